@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gaussian samples/sec of the red-black Gibbs sweep on a 512^3 DMDA (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+A "step" is ONE SAMPLE = one forward Gibbs sweep (= both colour passes, noise generated in-kernel) of the
+sorgibbs/mcgibbs sampler on the 7-point operator of MatAssembleShiftedLaplaceFD (reference src/problems.c:14-75,
+3-D analogue), kappa = 10, b = 1, x0 = 0, omega = 1 (reference examples/ex1.c:88,109), vectors resident in HBM
+in the library's colour-partitioned layout.  N ranks split the SAME 512^3 grid into z-slabs ("strong" scaling)
+and exchange one halo plane per colour per neighbour over RCCL.
+
+The JSON line also carries
+  roofline     -- dominant kernel (grid_color_sweep_kernel, one colour pass): algorithmic bytes per launch
+                  (24 B/unknown/sweep, SURVEY.md 8(d), x N/2 unknowns per launch = 12 N) / the average launch
+                  duration measured here with HIP events on the launch stream, against the 8 TB/s HBM3E peak;
+  cpu_baseline -- the CPU restatement of the reference's serial path (oracle/, lexicographic sweep + Box-Muller
+                  noise, 1 core), timed on a bounded sample; reported, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(nsub: int = 256, nfull: int = 512, samples: int = 8) -> dict:
+    """Serial reference path (one colour = lexicographic Gauss-Seidel, reference src/mc_sor.c:397-410,256-271;
+    noise per reference src/parmgmc.c:99-110; RHS per src/pc_mcgibbs.c:119-128) on an nsub^3 sub-grid, 1 core,
+    built -O3 -march=native.  value = 512^3-equivalent samples/s (rate on the sub-grid x (nsub/nfull)^3)."""
+    import numpy as np
+
+    import oracle as O
+
+    L = O.lib(native=True)
+    A = O.shifted_laplace(nsub, nsub, nsub, 10.0)
+    n = A.n
+    dp = O.diag_pointers(A)
+    idg, sd = O.idiag(A, 1.0), O.sqrtdiag(A, 1.0, True)
+    b, y, w = np.ones(n), np.zeros(n), np.zeros(n)
+    L.orc_gibbs_sample_serial(n, A.rowptr, A.colidx, A.vals, dp, idg, sd, 1.0, b, y, w, 0xCAFE, 0)  # warm-up
+    t0 = time.perf_counter()
+    for s in range(samples):
+        L.orc_gibbs_sample_serial(n, A.rowptr, A.colidx, A.vals, dp, idg, sd, 1.0, b, y, w, 0xCAFE, 1 + s)
+    dt = time.perf_counter() - t0
+    rate_sub = samples / dt
+    return {
+        "value": rate_sub * (nsub / nfull) ** 3,
+        "unit": "samples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{samples} lexicographic Gibbs samples (CSR sweep + Box-Muller noise) on a {nsub}^3 sub-grid = 1/{(nfull // nsub) ** 3} of the workload, {dt:.1f} s on 1 core; value = sub-grid rate x {(nsub / nfull) ** 3:g}",
+        "achieved_GBps_csr_model": (12 * len(A.vals) + 40 * n) * rate_sub / 1e9,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=512, help="grid points per direction (default: the BASELINE 512^3)")
+    ap.add_argument("--omega", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=256)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from parmgmc_amd.dist import DistGridSampler
+
+    n = args.n
+    smp = DistGridSampler(n, n, n, 10.0, rank, world, omega=args.omega)
+    g = smp.grid
+    nat_b = torch.ones(g.n, dtype=torch.float64, device="cuda")
+    b = g.to_cvec(nat_b)
+    del nat_b
+    y = g.new_cvec()  # x0 = 0
+    seed = 0xCAFE
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctr = smp.sample_cvec(b, y, args.warmup, seed, 0)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    ctr = smp.sample_cvec(b, y, args.steps, seed, ctr)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream is the one passed to the C-ABI)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    finite = bool(torch.isfinite(y).all().item())
+
+    if rank == 0:
+        N_total = n * n * n
+        N_local = g.n
+        launches = 2 * args.steps  # one launch per colour
+        t_launch = dev_ms * 1e-3 / launches
+        alg_bytes_per_launch = (24 if args.omega == 1.0 else 32) * N_local / 2
+        achieved = alg_bytes_per_launch / t_launch / 1e9
+        out = {
+            "metric": "Gaussian samples/sec on 512^3 3D DMDA (7-pt Laplacian precision, red-black Gibbs sweep = 1 sorgibbs sample)",
+            "value": args.steps / dt,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{n}^3 DMDA, 7-point shifted Laplacian (kappa=10, h2=1/(n-1)^2), b=1, x0=0, omega={args.omega:g}, forward red-black Gibbs sweep with in-kernel Philox4x32-10 + Box-Muller noise", "unknowns": N_total, "decomposition": f"{world} z-slab(s)", "halo": "none" if world == 1 else "1 plane/colour/neighbour over RCCL send/recv"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "grid_color_sweep_kernel", "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_us": t_launch * 1e6, "note": "24 B/unknown/sweep (read y, write y, read b once; SURVEY 8(d)) x N/2 unknowns per colour launch; duration = HIP-event time of the timed region / launches"},
+            "finite": finite,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, n)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/*
+ * parmgmc_hip.h -- C-ABI of the MI355X (gfx950) implementation of ParMGMC's Gibbs/SOR hot path.
+ *
+ * Drop-in boundary.  Every entry point replaces one interface of the reference (nilsfriess/ParMGMC; all
+ * file:line citations are relative to that repository) on RAW arrays instead of PETSc objects: plain
+ * pointers and sizes, `int` status codes, no PETSc, no torch, no C++ types.  A PETSc build binds these
+ * through the adapter shown in INTEGRATION.md (MatSeqAIJGetCSRAndMemType / VecGetArray... hand over exactly
+ * the arrays named here, reference src/mc_sor.c:250-255).
+ *
+ * Conventions
+ *   - status: 0 = success (PETSC_SUCCESS); non-zero values use PETSc's PetscErrorCode numbers so that the
+ *     adapter can return them unchanged (values from petscerror.h, PETSc source not present here).
+ *     Nothing throws, nothing aborts, nothing is printed; pmg_last_error_string() gives the message.
+ *   - "host" pointers are ordinary memory and are only read during the call (borrowed, never kept, like
+ *     the reference's borrowed Mat arrays, src/pc_sorgibbs.c:35-38); "dev" pointers are HBM addresses of
+ *     the current HIP device (hipMalloc / torch tensor.data_ptr()).
+ *   - indices are 32-bit (PetscInt default), scalars are double (PetscScalar = PetscReal = double).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All device work is enqueued on
+ *     it and NOT synchronised: calls return as soon as the work is queued unless stated otherwise.
+ *   - objects are not thread safe (the reference is single threaded per rank, src/parmgmc.c:38-42).
+ */
+#ifndef PARMGMC_HIP_H
+#define PARMGMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* status codes (PetscErrorCode numbering)                                                                 */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef int pmg_status;
+#define PMG_SUCCESS 0
+#define PMG_ERR_MEM 55            /* PETSC_ERR_MEM            */
+#define PMG_ERR_SUP 56            /* PETSC_ERR_SUP            */
+#define PMG_ERR_ORDER 58          /* PETSC_ERR_ORDER          */
+#define PMG_ERR_ARG_SIZ 60        /* PETSC_ERR_ARG_SIZ        */
+#define PMG_ERR_ARG_WRONG 62      /* PETSC_ERR_ARG_WRONG      */
+#define PMG_ERR_ARG_OUTOFRANGE 63 /* PETSC_ERR_ARG_OUTOFRANGE */
+#define PMG_ERR_ARG_WRONGSTATE 73 /* PETSC_ERR_ARG_WRONGSTATE */
+#define PMG_ERR_LIB 76            /* PETSC_ERR_LIB            */
+#define PMG_ERR_PLIB 77           /* PETSC_ERR_PLIB           */
+#define PMG_ERR_MAT_CH_ZRPVT 81   /* PETSC_ERR_MAT_CH_ZRPVT   */
+#define PMG_ERR_ARG_NULL 85       /* PETSC_ERR_ARG_NULL       */
+#define PMG_ERR_ARG_UNKNOWN_TYPE 86 /* PETSC_ERR_ARG_UNKNOWN_TYPE */
+#define PMG_ERR_GPU 97            /* PETSC_ERR_GPU            */
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *pmg_last_error_string(void);
+/* Library version "major.minor.patch" and the GPU architecture it was compiled for ("gfx950"). */
+const char *pmg_version(void);
+const char *pmg_gpu_arch(void);
+
+/* MatSORType values accepted by the reference (src/mc_sor.c:427): PETSc's SOR_FORWARD_SWEEP = 1,
+   SOR_BACKWARD_SWEEP = 2, SOR_SYMMETRIC_SWEEP = 3.  Anything else -> PMG_ERR_SUP. */
+#define PMG_SOR_FORWARD_SWEEP 1
+#define PMG_SOR_BACKWARD_SWEEP 2
+#define PMG_SOR_SYMMETRIC_SWEEP 3
+
+/* Colouring rules (reference: one colour in serial, src/mc_sor.c:397-410; PETSc JP in parallel, :383-395).
+   A GPU sweep needs a VALID distance-1 colouring, so the serial "one colour" rule is replaced by LEXLEVELS,
+   which reproduces the same lexicographic Gauss-Seidel result update for update. */
+#define PMG_COLORING_GREEDY 0    /* first-fit in natural row order (deterministic; replaces randomised JP)   */
+#define PMG_COLORING_LEXLEVELS 1 /* dependency levels of the natural-order sweep == serial reference / MatSOR */
+#define PMG_COLORING_USER 2      /* caller-supplied ISColoringValue array, validated                          */
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* MCSOR on an assembled AIJ matrix: replaces include/parmgmc/mc_sor.h:17-30                               */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef struct pmg_mcsor_s *pmg_mcsor; /* opaque, like `struct _MCSOR { void *ctx; }` (mc_sor.h:17-19) */
+
+/* MCSORCreate(Mat, MCSOR*) (src/mc_sor.c:618-642) for a MATSEQAIJ given as host CSR (the arrays of
+   MatSeqAIJGetCSRAndMemType, src/mc_sor.c:250).  Copies nothing yet; the arrays must stay valid until
+   pmg_mcsor_setup returns.  omega = 1, sweep = forward, colouring = GREEDY. */
+pmg_status pmg_mcsor_create_csr(int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host, pmg_mcsor *mc);
+/* Choose the colouring before setup.  user_colors_host (n entries, colours 0..ncolors-1) only for USER. */
+pmg_status pmg_mcsor_set_coloring(pmg_mcsor mc, int rule, const int32_t *user_colors_host);
+/* MCSORSetUp (src/mc_sor.c:553-605): diagonal pointers (:126-150), colouring (:441-454), idiag (:114-124);
+   builds the colour-partitioned sliced-ELL copy and uploads it.  Synchronous. */
+pmg_status pmg_mcsor_setup(pmg_mcsor mc);
+/* MCSORSetOmega (src/mc_sor.c:412-420); takes effect at the next apply (omega_changed, :222). */
+pmg_status pmg_mcsor_set_omega(pmg_mcsor mc, double omega);
+/* MCSORSetSweepType / MCSORGetSweepType (src/mc_sor.c:422-439). */
+pmg_status pmg_mcsor_set_sweep_type(pmg_mcsor mc, int type);
+pmg_status pmg_mcsor_get_sweep_type(pmg_mcsor mc, int *type);
+/* MCSORGetNumColors (src/mc_sor.c:607-616) and MCSORGetISColoring (:92-99; writes n colour values). */
+pmg_status pmg_mcsor_get_num_colors(pmg_mcsor mc, int32_t *ncolors);
+pmg_status pmg_mcsor_get_coloring(pmg_mcsor mc, int32_t *colors_host);
+/* MCSORApply(mc, b, y) (src/mc_sor.c:216-239): one deterministic sweep of the current type, y in/out,
+   vectors in the matrix's own (natural) row numbering on the device. */
+pmg_status pmg_mcsor_apply(pmg_mcsor mc, const double *b_dev, double *y_dev, void *stream);
+/* The sample loop of PCApplyRichardson_MulticolorGibbs (src/pc_mcgibbs.c:155-188) without the callback:
+   `its` times { w = xi*sqrtdiag + b ; sweep }, symmetric = forward + backward with two fresh draws
+   (:172-181).  scaled != 0: sqrtdiag carries sqrt((2-omega)/omega) (mcgibbs, :142-153); scaled == 0 is
+   PCSORGibbsSample (src/pc_sorgibbs.c:76-103, requires omega == 1).  Draw d of the call uses noise
+   counter `counter0 + d`; returns the next free counter in *counter_out (may be NULL). */
+pmg_status pmg_mcsor_sample(pmg_mcsor mc, const double *b_dev, double *y_dev, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+/* r = b - A y (PCMGResidualDefault / src/pc_gamgmc.c:253-254), natural numbering. */
+pmg_status pmg_mcsor_residual(pmg_mcsor mc, const double *b_dev, const double *y_dev, double *r_dev, void *stream);
+/* MCSORDestroy (src/mc_sor.c:60-90); *mc = NULL afterwards; NULL handle is a no-op. */
+pmg_status pmg_mcsor_destroy(pmg_mcsor *mc);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Matrix-free MCSOR on a DMDA grid: the same interface for the operator of                                */
+/* MatAssembleShiftedLaplaceFD (src/problems.c:14-75; 3-D analogue, nz = 1 is the reference 2-D matrix)    */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef struct pmg_grid_s *pmg_grid;
+
+/* One device owns planes [kz0, kz0+nz) of an nx*ny*nzg grid (single device: kz0 = 0, nz = nzg).
+   Red-black colouring c = (i+j+k)&1 (valid for the 5/7-point star), omega = 1, sweep = forward. */
+pmg_status pmg_grid_create(int32_t nx, int32_t ny, int32_t nzg, int32_t kz0, int32_t nz, double kappa, pmg_grid *g);
+pmg_status pmg_grid_set_omega(pmg_grid g, double omega);
+pmg_status pmg_grid_set_sweep_type(pmg_grid g, int type);
+pmg_status pmg_grid_get_sweep_type(pmg_grid g, int *type);
+pmg_status pmg_grid_get_num_colors(pmg_grid g, int32_t *ncolors);
+/* colours of the owned points in DMDA natural order (i fastest), nx*ny*nz values */
+pmg_status pmg_grid_get_coloring(pmg_grid g, int32_t *colors_host);
+/* Number of doubles of a colour-partitioned device vector ("cvec") of this grid, ghost planes included. */
+pmg_status pmg_grid_cvec_len(pmg_grid g, int64_t *len);
+/* natural (DMDA global vector of the owned planes, i fastest) <-> cvec */
+pmg_status pmg_grid_to_cvec(pmg_grid g, const double *nat_dev, double *cvec_dev, void *stream);
+pmg_status pmg_grid_from_cvec(pmg_grid g, const double *cvec_dev, double *nat_dev, void *stream);
+/* MCSORApply on natural-order device vectors (converts in and out; convenience / PCSHELL route,
+   examples/ex3.c:59-67). */
+pmg_status pmg_grid_apply(pmg_grid g, const double *b_nat_dev, double *y_nat_dev, void *stream);
+/* MCSORApply / sample loop / residual directly on cvecs (no conversion; what the V-cycle and bench use). */
+pmg_status pmg_grid_apply_cvec(pmg_grid g, const double *b_cvec, double *y_cvec, void *stream);
+pmg_status pmg_grid_sample_cvec(pmg_grid g, const double *b_cvec, double *y_cvec, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+pmg_status pmg_grid_residual_cvec(pmg_grid g, const double *b_cvec, const double *y_cvec, double *r_cvec, void *stream);
+/* One colour of one sweep (the body of the colour loop of MCSORApply_MPIAIJ, src/mc_sor.c:317-340), for
+   callers that interleave the per-colour ghost exchange themselves (multi-GPU).  noisy != 0 forms
+   w = xi*sqrtdiag + b with noise counter `counter`; the colour-`color` points read the OTHER colour, so the
+   ghost planes of colour 1-color must be current. */
+pmg_status pmg_grid_sweep_color_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const double *b_cvec, double *y_cvec, void *stream);
+/* Where the halo of colour `color` lives inside a cvec (offsets and count in doubles): the owned boundary
+   plane on `side` (0 = low k, 1 = high k) that the neighbour needs, and the ghost plane on that side that
+   receives the neighbour's plane.  A plane of one colour is one contiguous block, so the exchange that replaces
+   the reference's per-colour VecScatter (src/mc_sor.c:318-319) is a single contiguous send/recv. */
+pmg_status pmg_grid_halo_plane(pmg_grid g, int color, int side, int64_t *owned_offset, int64_t *ghost_offset, int64_t *count);
+/* Sample loop on natural-order vectors: converts in once, runs `its` sweeps, converts out once. */
+pmg_status pmg_grid_sample(pmg_grid g, const double *b_nat_dev, double *y_nat_dev, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+pmg_status pmg_grid_destroy(pmg_grid *g);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* VecSetRandomStandardNormal (src/parmgmc.c:70-116) on the counter-based source: entry r gets the (r&1)    */
+/* branch of the Box-Muller pair with Philox counter {r>>1, sweep}, key = seed.                            */
+/* ------------------------------------------------------------------------------------------------------ */
+pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t seed, uint64_t counter, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARMGMC_HIP_H */

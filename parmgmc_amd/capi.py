@@ -1,0 +1,89 @@
+"""ctypes binding of include/parmgmc_hip.h.  No fallback: a missing library is an ImportError."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+_ROOT = _PKG.parent
+
+SOR_FORWARD_SWEEP, SOR_BACKWARD_SWEEP, SOR_SYMMETRIC_SWEEP = 1, 2, 3
+COLORING_GREEDY, COLORING_LEXLEVELS, COLORING_USER = 0, 1, 2
+
+
+class PMGError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pmg status {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> Path:
+    return _PKG / "libparmgmc_hip.so"
+
+
+def header_path() -> Path:
+    return _ROOT / "include" / "parmgmc_hip.h"
+
+
+def declared_symbols() -> list[str]:
+    """Every function name the public header declares (used by the export test)."""
+    text = header_path().read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pmg_[a-z0-9_]+)\s*\(", text)))
+
+
+def _load() -> C.CDLL:
+    p = library_path()
+    if not p.exists():
+        raise ImportError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` " "(hipcc --offload-arch=gfx950). parmgmc_amd has no CPU fallback.")
+    return C.CDLL(str(p))
+
+
+lib = _load()
+
+_vp, _i32, _i64, _u64, _dbl, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_int
+_sig = {
+    "pmg_last_error_string": (C.c_char_p, []),
+    "pmg_version": (C.c_char_p, []),
+    "pmg_gpu_arch": (C.c_char_p, []),
+    "pmg_mcsor_create_csr": (_int, [_i32, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pmg_mcsor_set_coloring": (_int, [_vp, _int, _vp]),
+    "pmg_mcsor_setup": (_int, [_vp]),
+    "pmg_mcsor_set_omega": (_int, [_vp, _dbl]),
+    "pmg_mcsor_set_sweep_type": (_int, [_vp, _int]),
+    "pmg_mcsor_get_sweep_type": (_int, [_vp, C.POINTER(_int)]),
+    "pmg_mcsor_get_num_colors": (_int, [_vp, C.POINTER(_i32)]),
+    "pmg_mcsor_get_coloring": (_int, [_vp, _vp]),
+    "pmg_mcsor_apply": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_mcsor_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
+    "pmg_mcsor_residual": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pmg_mcsor_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_grid_create": (_int, [_i32, _i32, _i32, _i32, _i32, _dbl, C.POINTER(_vp)]),
+    "pmg_grid_set_omega": (_int, [_vp, _dbl]),
+    "pmg_grid_set_sweep_type": (_int, [_vp, _int]),
+    "pmg_grid_get_sweep_type": (_int, [_vp, C.POINTER(_int)]),
+    "pmg_grid_get_num_colors": (_int, [_vp, C.POINTER(_i32)]),
+    "pmg_grid_get_coloring": (_int, [_vp, _vp]),
+    "pmg_grid_cvec_len": (_int, [_vp, C.POINTER(_i64)]),
+    "pmg_grid_to_cvec": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_grid_from_cvec": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_grid_apply": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_grid_apply_cvec": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_grid_sample_cvec": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
+    "pmg_grid_residual_cvec": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pmg_grid_sweep_color_cvec": (_int, [_vp, _int, _int, _int, _u64, _u64, _vp, _vp, _vp]),
+    "pmg_grid_halo_plane": (_int, [_vp, _int, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "pmg_grid_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
+    "pmg_grid_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_vec_set_random_standard_normal": (_int, [_i64, _vp, _u64, _u64, _vp]),
+}
+for _name, (_res, _args) in _sig.items():
+    _f = getattr(lib, _name)
+    _f.restype, _f.argtypes = _res, _args
+
+
+def check(status: int) -> None:
+    """PetscCall analogue: raise on a non-zero status with the library's message."""
+    if status != 0:
+        raise PMGError(status, lib.pmg_last_error_string().decode())

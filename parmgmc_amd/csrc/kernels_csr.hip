@@ -1,0 +1,166 @@
+// Multicolour Gibbs/SOR sweep on a colour-partitioned sliced-ELL copy of an AIJ matrix (gfx950).
+//
+// Replaces MCSORApply_SEQAIJ (reference src/mc_sor.c:241-296), the row kernel of PCPARSOR
+// (SORLocalForwardSweepIS, reference src/pc_parsor.c:666-701) and PETSc's MatSOR forward sweep as called at
+// reference src/pc_sorgibbs.c:94, for any matrix and any valid colouring, with the noisy right-hand side of
+// PrepareRHS_Default (reference src/pc_mcgibbs.c:119-128) formed in registers.
+//
+// Layout: rows are renumbered so that the rows of one colour are contiguous and start on a 64-row slice
+// boundary; one wavefront owns one slice and streams its off-diagonal entries column-major, so that the 64
+// lanes read 64 consecutive doubles (vals) and 64 consecutive ints (cols) per step -- fully coalesced -- and
+// only the gather y[col] is irregular.  Entries keep the CSR storage order of their row (lower part, then
+// upper part) so the sum is bit-identical to the reference loop; pad entries have value 0 and point at the
+// row itself.  Vectors handled here are in the permuted numbering.
+#include <hip/hip_runtime.h>
+#include "pmg_kernels.h"
+#include "pmg_rng.hpp"
+
+namespace {
+
+template <bool NOISY>
+__global__ __launch_bounds__(256) void sell_color_sweep_kernel(pmgk_sell S, int slice0, int nsl, double omega, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, double *y)
+{
+  const int lane = threadIdx.x & 63;
+  const int sl   = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (sl >= nsl) return;
+  const int     s   = slice0 + sl;
+  const int     row = s * 64 + lane;
+  const int64_t off = S.soff[s];
+  const int     w   = S.swidth[s];
+  const int     org = S.orig[row];
+  double        sum = b[row];
+  if (NOISY) {
+    // row stream: entries (2q, 2q+1) of the ORIGINAL numbering share one Box-Muller pair
+    const uint32_t uorg = org < 0 ? 0u : (uint32_t)org;
+    double         z0, z1;
+    pmg::normal_pair(uorg >> 1, 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, z0, z1);
+    const double xi = (uorg & 1u) ? z1 : z0;
+    sum             = xi * S.sqrtdiag[row] + sum;
+  }
+  const double  *v = S.vals + off + lane;
+  const int32_t *c = S.cols + off + lane;
+  for (int j = 0; j < w; ++j) {
+    const double  a  = v[(int64_t)j * 64];
+    const int32_t cj = c[(int64_t)j * 64];
+    sum              = sum - a * y[cj];
+  }
+  if (org >= 0) y[row] = one_minus_omega * y[row] + S.idiag[row] * sum;
+  (void)omega;
+}
+
+// r = b - A y in the permuted numbering; the diagonal term is added last (the reference's residual goes
+// through PETSc MatMult whose summation order is storage order; differences are O(eps)).
+__global__ __launch_bounds__(256) void sell_residual_kernel(pmgk_sell S, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+{
+  const int lane = threadIdx.x & 63;
+  const int s    = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (s >= S.nslices) return;
+  const int      row = s * 64 + lane;
+  const int64_t  off = S.soff[s];
+  const int      w   = S.swidth[s];
+  const double  *v   = S.vals + off + lane;
+  const int32_t *c   = S.cols + off + lane;
+  double         sum = 0.0;
+  for (int j = 0; j < w; ++j) sum = sum + v[(int64_t)j * 64] * y[c[(int64_t)j * 64]];
+  sum    = sum + S.diag[row] * y[row];
+  r[row] = S.orig[row] >= 0 ? b[row] - sum : 0.0;
+}
+
+__global__ void permute_in_kernel(int32_t ld, const int32_t *__restrict__ orig, const double *__restrict__ nat, double *__restrict__ perm)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ld) return;
+  const int o = orig[r];
+  perm[r]     = o >= 0 ? nat[o] : 0.0;
+}
+
+__global__ void permute_out_kernel(int32_t ld, const int32_t *__restrict__ orig, const double *__restrict__ perm, double *__restrict__ nat)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ld) return;
+  const int o = orig[r];
+  if (o >= 0) nat[o] = perm[r];
+}
+
+// One wavefront per row group: plain CSR product for the (short-row) transfer operators.
+__global__ __launch_bounds__(256) void csr_spmv_kernel(int32_t nrows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ vals, double alpha, const double *__restrict__ x, double beta, double *__restrict__ y)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  double sum = 0.0;
+  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) sum = sum + vals[k] * x[colidx[k]];
+  y[r] = beta == 0.0 ? alpha * sum : alpha * sum + beta * y[r];
+}
+
+__global__ void axpy_kernel(int64_t n, double alpha, const double *__restrict__ x, double *__restrict__ y)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = y[i] + alpha * x[i];
+}
+
+__global__ void fill_normal_rows_kernel(int64_t n, uint32_t key0, uint32_t key1, uint64_t sweep, double *__restrict__ xi)
+{
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * q >= n) return;
+  double z0, z1;
+  pmg::normal_pair((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, z0, z1);
+  xi[2 * q] = z0;
+  if (2 * q + 1 < n) xi[2 * q + 1] = z1;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
+
+} // namespace
+
+extern "C" int pmgk_sell_color_sweep(const pmgk_sell *S, int slice0, int nsl, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream)
+{
+  if (nsl <= 0) return 0;
+  const dim3 block(256), grid((nsl + 3) / 4);
+  const double om1 = 1. - omega;
+  if (noisy) hipLaunchKernelGGL((sell_color_sweep_kernel<true>), grid, block, 0, (hipStream_t)stream, *S, slice0, nsl, omega, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
+  else hipLaunchKernelGGL((sell_color_sweep_kernel<false>), grid, block, 0, (hipStream_t)stream, *S, slice0, nsl, omega, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
+  return launch_status();
+}
+
+extern "C" int pmgk_sell_residual(const pmgk_sell *S, const double *b, const double *y, double *r, void *stream)
+{
+  if (S->nslices <= 0) return 0;
+  hipLaunchKernelGGL(sell_residual_kernel, dim3((S->nslices + 3) / 4), dim3(256), 0, (hipStream_t)stream, *S, b, y, r);
+  return launch_status();
+}
+
+extern "C" int pmgk_permute_in(int32_t ld, const int32_t *orig, const double *nat, double *perm, void *stream)
+{
+  if (ld <= 0) return 0;
+  hipLaunchKernelGGL(permute_in_kernel, dim3((ld + 255) / 256), dim3(256), 0, (hipStream_t)stream, ld, orig, nat, perm);
+  return launch_status();
+}
+
+extern "C" int pmgk_permute_out(int32_t ld, const int32_t *orig, const double *perm, double *nat, void *stream)
+{
+  if (ld <= 0) return 0;
+  hipLaunchKernelGGL(permute_out_kernel, dim3((ld + 255) / 256), dim3(256), 0, (hipStream_t)stream, ld, orig, perm, nat);
+  return launch_status();
+}
+
+extern "C" int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, double alpha, const double *x, double beta, double *y, void *stream)
+{
+  if (nrows <= 0) return 0;
+  hipLaunchKernelGGL(csr_spmv_kernel, dim3((nrows + 255) / 256), dim3(256), 0, (hipStream_t)stream, nrows, rowptr, colidx, vals, alpha, x, beta, y);
+  return launch_status();
+}
+
+extern "C" int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream)
+{
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, alpha, x, y);
+  return launch_status();
+}
+
+extern "C" int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream)
+{
+  if (n <= 0) return 0;
+  const int64_t pairs = (n + 1) / 2;
+  hipLaunchKernelGGL(fill_normal_rows_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, xi);
+  return launch_status();
+}

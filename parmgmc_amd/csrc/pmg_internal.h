@@ -1,0 +1,46 @@
+/* Host-side internals of libparmgmc_hip (C11). */
+#ifndef PMG_INTERNAL_H
+#define PMG_INTERNAL_H
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/parmgmc_hip.h"
+#include "pmg_kernels.h"
+
+#define PMG_VERSION_STRING "0.1.0"
+
+/* Records file:line + message for pmg_last_error_string() and returns `code` (PetscCheck analogue:
+   reference code raises through PetscCheck(cond, comm, PETSC_ERR_*, fmt...), e.g. src/mc_sor.c:427). */
+pmg_status pmg_set_error(pmg_status code, const char *file, int line, const char *fmt, ...);
+
+#define PMG_FAIL(code, ...) return pmg_set_error((code), __FILE__, __LINE__, __VA_ARGS__)
+#define PMG_CHECK(cond, code, ...) \
+  do { \
+    if (!(cond)) return pmg_set_error((code), __FILE__, __LINE__, __VA_ARGS__); \
+  } while (0)
+/* PetscCall analogue */
+#define PMG_CALL(expr) \
+  do { \
+    pmg_status pmg_s_ = (expr); \
+    if (pmg_s_) return pmg_s_; \
+  } while (0)
+#define PMG_HIP(expr) \
+  do { \
+    hipError_t pmg_e_ = (expr); \
+    if (pmg_e_ != hipSuccess) return pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "%s: %s", #expr, hipGetErrorString(pmg_e_)); \
+  } while (0)
+#define PMG_KERNEL(expr) \
+  do { \
+    if ((expr) != 0) return pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed: %s", #expr); \
+  } while (0)
+
+static inline int pmg_sweep_type_ok(int t) { return t == PMG_SOR_FORWARD_SWEEP || t == PMG_SOR_BACKWARD_SWEEP || t == PMG_SOR_SYMMETRIC_SWEEP; }
+
+/* device allocation helpers (zero-filled) */
+pmg_status pmg_dev_alloc(void **p, size_t bytes);
+pmg_status pmg_dev_upload(void **p, const void *host, size_t bytes);
+void       pmg_dev_free(void *p);
+
+#endif

@@ -1,0 +1,80 @@
+/* Internal launch interface between the host C layer and the HIP kernels (not part of the public C-ABI).
+   Plain C so that the host side (gcc, C11) and the device side (hipcc) share one declaration. */
+#ifndef PMG_KERNELS_H
+#define PMG_KERNELS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Colour-partitioned storage of a vector on an nx*ny*nz vertex grid ("cvec").
+
+   Points are split by parity c = (i+j+kg)&1 (kg = global plane index).  Each colour is stored as its own
+   array of planes; a plane holds ny grid lines of `sx` doubles; along a line (j,k) the points of colour c are
+   i = 2m + p, p = (c+j+kg)&1, and sit at m = 0,1,...  One ghost plane below and one above the nz owned
+   planes hold the neighbouring device's boundary planes (multi-GPU) and are never read at a physical
+   boundary.  Element (c, k, j, m) lives at  c*cs + (k+1)*sp + j*sx + m.  sx is a multiple of 16 doubles
+   (128 B) so that every line starts on a cache line; pad slots are zero and never written. */
+typedef struct {
+  int32_t nx, ny, nz;  /* owned extent (nz = owned planes) */
+  int32_t kz0, nzg;    /* global index of owned plane 0, global number of planes */
+  int32_t sx;          /* line stride (doubles) */
+  int64_t sp;          /* plane stride = ny*sx */
+  int64_t cs;          /* colour stride = (nz+2)*sp */
+} pmgk_grid_layout;
+
+/* Operator + sweep parameters of the matrix-free 7-point kernel: the matrix of
+   MatAssembleShiftedLaplaceFD (reference src/problems.c:14-75) generalised to 3-D.  Off-diagonals are -h2
+   for every in-domain neighbour; the diagonal takes one of 7 values indexed by the number of in-domain
+   neighbours, so idiag (= (1/d)*omega, reference src/mc_sor.c:114-124) and sqrtdiag (= sqrt|d| *
+   sqrt((2-omega)/omega), reference src/pc_mcgibbs.c:142-153) are 7-entry tables computed on the host with
+   the reference's rounding sequence. */
+typedef struct {
+  double   h2;
+  double   one_minus_omega;
+  double   idiag[8];
+  double   sqrtdiag[8];
+  double   diag[8];
+  uint32_t key0, key1; /* Philox key = seed */
+  uint64_t sweep;      /* noise counter of this sweep */
+  int32_t  noisy;      /* 0: w = b (MCSORApply); 1: w = xi*sqrtdiag + b (PrepareRHS_Default) */
+  int32_t  omega_is_one;
+} pmgk_grid_op;
+
+int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, const double *b_cvec, double *y_cvec, void *stream);
+int pmgk_grid_to_cvec(const pmgk_grid_layout *L, const double *nat, double *cvec, void *stream);
+int pmgk_grid_from_cvec(const pmgk_grid_layout *L, const double *cvec, double *nat, void *stream);
+/* r = b - A y on cvecs (PCMGResidualDefault / src/pc_gamgmc.c:253-254) */
+int pmgk_grid_residual(const pmgk_grid_layout *L, const pmgk_grid_op *op, const double *b_cvec, const double *y_cvec, double *r_cvec, void *stream);
+
+/* Sliced-ELL multicolour operator ("colour-partitioned CSR"): rows permuted so that each colour is
+   contiguous and starts on a 64-row slice boundary; slice s stores its off-diagonal entries column-major
+   (entry j of lane l at soff[s] + j*64 + l) in the CSR storage order of the original row. */
+typedef struct {
+  int32_t        n;        /* rows (original) */
+  int32_t        ld;       /* padded length of a permuted vector (multiple of 64) */
+  int32_t        nslices;
+  const int64_t *soff;     /* [nslices+1] device */
+  const int32_t *swidth;   /* [nslices] device */
+  const double  *vals;     /* device */
+  const int32_t *cols;     /* device, permuted numbering */
+  const double  *idiag;    /* [ld] device, 0 in pad rows */
+  const double  *sqrtdiag; /* [ld] device */
+  const double  *diag;     /* [ld] device */
+  const int32_t *orig;     /* [ld] device: original row of permuted row, -1 in pad rows */
+} pmgk_sell;
+
+int pmgk_sell_color_sweep(const pmgk_sell *S, int slice0, int nsl, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream);
+int pmgk_sell_residual(const pmgk_sell *S, const double *b, const double *y, double *r, void *stream);
+int pmgk_permute_in(int32_t ld, const int32_t *orig, const double *nat, double *perm, void *stream);
+int pmgk_permute_out(int32_t ld, const int32_t *orig, const double *perm, double *nat, void *stream);
+
+/* generic CSR product on device arrays: y = alpha*A x + beta*y  (rows in any layout) */
+int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, double alpha, const double *x, double beta, double *y, void *stream);
+int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);
+int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,189 @@
+"""Thin Python mirrors of the C-ABI objects, for tests and benchmarks.
+
+Device vectors are torch CUDA tensors (float64); only their ``data_ptr()`` and the current HIP stream cross
+the boundary.  The method names follow the reference API (include/parmgmc/mc_sor.h:21-30)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, lib
+
+
+def _stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    import torch
+
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), "need a contiguous float64 CUDA tensor"
+    return C.c_void_p(t.data_ptr())
+
+
+class MCSOR:
+    """MCSOR on an assembled AIJ matrix (reference include/parmgmc/mc_sor.h:21-30)."""
+
+    def __init__(self, rowptr, colidx, vals, coloring=capi.COLORING_GREEDY, user_colors=None):
+        self._rowptr = np.ascontiguousarray(rowptr, np.int32)
+        self._colidx = np.ascontiguousarray(colidx, np.int32)
+        self._vals = np.ascontiguousarray(vals, np.float64)
+        self.n = len(self._rowptr) - 1
+        self._h = C.c_void_p()
+        check(lib.pmg_mcsor_create_csr(self.n, self._rowptr.ctypes.data, self._colidx.ctypes.data, self._vals.ctypes.data, C.byref(self._h)))
+        uc = None
+        if user_colors is not None:
+            uc = np.ascontiguousarray(user_colors, np.int32)
+            coloring = capi.COLORING_USER
+        try:
+            check(lib.pmg_mcsor_set_coloring(self._h, coloring, None if uc is None else uc.ctypes.data))
+        except Exception:
+            self.destroy()
+            raise
+
+    def setup(self):
+        check(lib.pmg_mcsor_setup(self._h))
+        return self
+
+    def set_omega(self, omega: float):
+        check(lib.pmg_mcsor_set_omega(self._h, omega))
+
+    def set_sweep_type(self, t: int):
+        check(lib.pmg_mcsor_set_sweep_type(self._h, t))
+
+    def get_sweep_type(self) -> int:
+        t = C.c_int()
+        check(lib.pmg_mcsor_get_sweep_type(self._h, C.byref(t)))
+        return t.value
+
+    def get_num_colors(self) -> int:
+        n = C.c_int32()
+        check(lib.pmg_mcsor_get_num_colors(self._h, C.byref(n)))
+        return n.value
+
+    def get_coloring(self) -> np.ndarray:
+        out = np.zeros(max(self.n, 1), np.int32)
+        check(lib.pmg_mcsor_get_coloring(self._h, out.ctypes.data))
+        return out[: self.n]
+
+    def apply(self, b, y):
+        check(lib.pmg_mcsor_apply(self._h, _ptr(b), _ptr(y), _stream()))
+
+    def sample(self, b, y, its: int, seed: int, counter0: int = 0, scaled: bool = True) -> int:
+        out = C.c_uint64()
+        check(lib.pmg_mcsor_sample(self._h, _ptr(b), _ptr(y), its, int(scaled), seed, counter0, C.byref(out), _stream()))
+        return out.value
+
+    def residual(self, b, y, r):
+        check(lib.pmg_mcsor_residual(self._h, _ptr(b), _ptr(y), _ptr(r), _stream()))
+
+    def destroy(self):
+        if self._h:
+            check(lib.pmg_mcsor_destroy(C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class GridMCSOR:
+    """Matrix-free MCSOR on a DMDA grid for the operator of MatAssembleShiftedLaplaceFD
+    (reference src/problems.c:14-75); owns planes [kz0, kz0+nz) of nx*ny*nzg."""
+
+    def __init__(self, nx, ny, nz=1, kappa=1.0, kz0=0, nz_owned=None):
+        self.nx, self.ny, self.nzg = nx, ny, nz
+        self.kz0, self.nz = kz0, (nz if nz_owned is None else nz_owned)
+        self._h = C.c_void_p()
+        check(lib.pmg_grid_create(nx, ny, nz, self.kz0, self.nz, kappa, C.byref(self._h)))
+        n = C.c_int64()
+        check(lib.pmg_grid_cvec_len(self._h, C.byref(n)))
+        self.cvec_len = n.value
+        self.n = nx * ny * self.nz
+
+    def new_cvec(self):
+        import torch
+
+        return torch.zeros(self.cvec_len, dtype=torch.float64, device="cuda")
+
+    def to_cvec(self, nat, out=None):
+        out = self.new_cvec() if out is None else out
+        check(lib.pmg_grid_to_cvec(self._h, _ptr(nat), _ptr(out), _stream()))
+        return out
+
+    def from_cvec(self, cvec, out=None):
+        import torch
+
+        out = torch.empty(self.n, dtype=torch.float64, device="cuda") if out is None else out
+        check(lib.pmg_grid_from_cvec(self._h, _ptr(cvec), _ptr(out), _stream()))
+        return out
+
+    def set_omega(self, omega: float):
+        check(lib.pmg_grid_set_omega(self._h, omega))
+
+    def set_sweep_type(self, t: int):
+        check(lib.pmg_grid_set_sweep_type(self._h, t))
+
+    def get_sweep_type(self) -> int:
+        t = C.c_int()
+        check(lib.pmg_grid_get_sweep_type(self._h, C.byref(t)))
+        return t.value
+
+    def get_num_colors(self) -> int:
+        n = C.c_int32()
+        check(lib.pmg_grid_get_num_colors(self._h, C.byref(n)))
+        return n.value
+
+    def get_coloring(self) -> np.ndarray:
+        out = np.zeros(self.n, np.int32)
+        check(lib.pmg_grid_get_coloring(self._h, out.ctypes.data))
+        return out
+
+    def apply(self, b, y):
+        check(lib.pmg_grid_apply(self._h, _ptr(b), _ptr(y), _stream()))
+
+    def apply_cvec(self, b, y):
+        check(lib.pmg_grid_apply_cvec(self._h, _ptr(b), _ptr(y), _stream()))
+
+    def sample(self, b, y, its: int, seed: int, counter0: int = 0, scaled: bool = True) -> int:
+        out = C.c_uint64()
+        check(lib.pmg_grid_sample(self._h, _ptr(b), _ptr(y), its, int(scaled), seed, counter0, C.byref(out), _stream()))
+        return out.value
+
+    def sample_cvec(self, b, y, its: int, seed: int, counter0: int = 0, scaled: bool = True) -> int:
+        out = C.c_uint64()
+        check(lib.pmg_grid_sample_cvec(self._h, _ptr(b), _ptr(y), its, int(scaled), seed, counter0, C.byref(out), _stream()))
+        return out.value
+
+    def sweep_color_cvec(self, color: int, b, y, noisy: bool = False, scaled: bool = True, seed: int = 0, counter: int = 0):
+        check(lib.pmg_grid_sweep_color_cvec(self._h, color, int(noisy), int(scaled), seed, counter, _ptr(b), _ptr(y), _stream()))
+
+    def halo_plane(self, color: int, side: int):
+        """(owned_offset, ghost_offset, count) in doubles inside a cvec."""
+        a, b, n = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.pmg_grid_halo_plane(self._h, color, side, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    def residual_cvec(self, b, y, r):
+        check(lib.pmg_grid_residual_cvec(self._h, _ptr(b), _ptr(y), _ptr(r), _stream()))
+
+    def destroy(self):
+        if self._h:
+            check(lib.pmg_grid_destroy(C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def vec_set_random_standard_normal(x, seed: int, counter: int = 0):
+    """VecSetRandomStandardNormal (reference src/parmgmc.c:70-116) on the counter-based source."""
+    check(lib.pmg_vec_set_random_standard_normal(x.numel(), _ptr(x), seed, counter, _stream()))
+    return x
