@@ -33,7 +33,23 @@ def declared_symbols() -> list[str]:
     return sorted(set(re.findall(r"\b(pmg_[a-z0-9_]+)\s*\(", text)))
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (soname without
+    version), libparmgmc_hip.so names the system one (libamdhip64.so.7): loaded naively the process gets two
+    runtimes and whichever initialises second sees "no ROCm-capable device".  Callers hand us torch tensors,
+    so make torch's runtime the process-global one BEFORE our library is mapped; the dynamic linker then binds
+    our hip* references to it (global scope is searched before a library's own dependencies)."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        return
+    cand = Path(torch.__file__).resolve().parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def _load() -> C.CDLL:
+    _share_torch_hip_runtime()
     p = library_path()
     if not p.exists():
         raise ImportError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` " "(hipcc --offload-arch=gfx950). parmgmc_amd has no CPU fallback.")
