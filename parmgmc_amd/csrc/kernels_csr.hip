@@ -20,6 +20,11 @@ namespace {
 template <bool NOISY>
 __global__ __launch_bounds__(256) void sell_color_sweep_kernel(pmgk_sell S, int slice0, int nsl, double omega, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, double *y)
 {
+  __shared__ pmg::LogTabEntry s_logtab[PMG_LOGTAB_SIZE];
+  if (NOISY) {
+    pmg::load_log_table(s_logtab);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int sl   = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (sl >= nsl) return;
@@ -33,7 +38,7 @@ __global__ __launch_bounds__(256) void sell_color_sweep_kernel(pmgk_sell S, int 
     // row stream: entries (2q, 2q+1) of the ORIGINAL numbering share one Box-Muller pair
     const uint32_t uorg = org < 0 ? 0u : (uint32_t)org;
     double         z0, z1;
-    pmg::normal_pair(uorg >> 1, 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, z0, z1);
+    pmg::normal_pair(uorg >> 1, 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
     const double xi = (uorg & 1u) ? z1 : z0;
     sum             = xi * S.sqrtdiag[row] + sum;
   }
@@ -100,10 +105,13 @@ __global__ void axpy_kernel(int64_t n, double alpha, const double *__restrict__ 
 
 __global__ void fill_normal_rows_kernel(int64_t n, uint32_t key0, uint32_t key1, uint64_t sweep, double *__restrict__ xi)
 {
+  __shared__ pmg::LogTabEntry s_logtab[PMG_LOGTAB_SIZE];
+  pmg::load_log_table(s_logtab);
+  __syncthreads();
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (2 * q >= n) return;
   double z0, z1;
-  pmg::normal_pair((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, z0, z1);
+  pmg::normal_pair((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
   xi[2 * q] = z0;
   if (2 * q + 1 < n) xi[2 * q + 1] = z1;
 }

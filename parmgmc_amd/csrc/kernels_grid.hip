@@ -13,20 +13,129 @@
 // a = -h2 the reference's "sum -= a*y" equals "sum += h2*y" bit for bit.  The file is compiled with
 // -ffp-contract=off (no FMA contraction), like the CPU oracle.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "pmg_kernels.h"
 #include "pmg_rng.hpp"
 
 namespace {
 
-struct d2 {
-  double x, y;
-};
+// first-class 16-byte vector: one global_load/store_dwordx4 that the optimiser cannot split per component
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ d2 ld2(const double *p) { return *reinterpret_cast<const d2 *>(p); }
 
+// wave-uniform double -> SGPR pair
+__device__ __forceinline__ double uniform(double v)
+{
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// Sweep of one colour.
+//
+// Block = 64 lanes along x (one wavefront = 128 consecutive points of this colour on one grid line = 256 grid
+// columns) x 4 grid lines of ONE plane; each thread owns two consecutive points (m = 2t, 2t+1: one 16-byte
+// load/store per array).  Measured on MI355X (tools/streambench.hip): a one-tile-per-block grid dispatched in
+// memory order streams at 6.1 TB/s for this read-2/write-1 mix, a grid-stride/marching loop only 4.4-5.1 TB/s,
+// so blocks are kept short and the dispatch order is what creates locality:
+//   * blockIdx % 8 selects the XCD under round-robin dispatch (speed heuristic only, nothing depends on it);
+//     XCD x gets the band of grid lines [x*band, (x+1)*band) of EVERY plane, in plane order, so the 6 reads a
+//     point makes of the other colour (same line, lines j-1/j+1, planes k-1/k+1) hit lines that the SAME XCD's
+//     L2 fetched a few hundred blocks earlier, and all 8 XCDs advance through the planes together, which keeps
+//     the set of open DRAM pages compact.
+// Boundary handling is branch-free: an absent neighbour is read from a clamped (valid, finite) address and
+// enters with coefficient 0 instead of h2, which adds an exact +0.
+template <bool NOISY, bool OMEGA1>
+__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+{
+  // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
+  // wave-uniform; readfirstlane tells the compiler, which then keeps the boundary logic on the scalar unit
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  __shared__ pmg::LogTabEntry s_logtab[NOISY ? 4 * PMG_LOGTAB_SIZE : 1];
+  const pmg::LogTabEntry     *tab = s_logtab + (NOISY ? ty * PMG_LOGTAB_SIZE : 0);
+  if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x);
+
+  // grid = (8*nbx, band, nz) in XCD-banded order [the linear block id is blockIdx.x mod 8, so blockIdx.x & 7
+  // is the XCD], or (nbx, nby, nz) in plain order
+  const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
+  const int k  = blockIdx.z;
+  const int t = bx * 64 + threadIdx.x;
+  const int j = by * 4 + ty;
+  if (j >= L.ny || 2 * t >= L.sx) return;
+  const int kg = k + L.kz0;
+  const int p  = (c + j + kg) & 1;
+  const int i0 = 4 * t + p, i1 = i0 + 2; // grid columns of the two points
+  if (i0 >= L.nx) return;
+  const bool v1 = i1 < L.nx;
+
+  const bool    hasS = j > 0, hasN = j < L.ny - 1, hasD = kg > 0, hasU = kg < L.nzg - 1;
+  const double  h2 = op.h2;
+  const int64_t line = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + 2 * t; // element (plane k, line j, m = 2t)
+  const double *yo   = y_other + line;
+  // p=0: left(0)=m' 2t-1 (ed), right(0)=2t,   left(1)=2t,   right(1)=2t+1
+  // p=1: left(0)=m' 2t,        right(0)=2t+1, left(1)=2t+1, right(1)=2t+2 (ed)
+  const int    eo = p ? (2 * t + 2 < L.sx ? 2 : 1) : (t > 0 ? -1 : 0); // clamped lane-neighbour offset
+  const d2     Vc = ld2(yo);
+  const double ed = yo[eo];
+  const d2     oS = ld2(yo - (hasS ? L.sx : 0));
+  const d2     oN = ld2(yo + (hasN ? L.sx : 0));
+  const d2     oD = ld2(yo - (hasD ? L.sp : 0));
+  const d2     oU = ld2(yo + (hasU ? L.sp : 0));
+  const d2     bb = ld2(b_own + line);
+
+  const double L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
+  const bool   hasW0 = i0 > 0, hasE0 = i0 < L.nx - 1, hasE1 = i1 < L.nx - 1;
+  // diagonal-dependent constants: the point has nyz in-domain y/z neighbours (wave-uniform) plus 1 or 2 in x
+  const int    nyz = (int)hasS + (int)hasN + (int)hasD + (int)hasU;
+  const bool   two0 = hasW0 && hasE0, two1 = hasE1;
+  const double idA = uniform(op.idiag[nyz + 1]), idB = uniform(op.idiag[nyz + 2]);
+  const double idg0 = two0 ? idB : idA, idg1 = two1 ? idB : idA;
+  const double hS = hasS ? h2 : 0.0, hN = hasN ? h2 : 0.0, hD = hasD ? h2 : 0.0, hU = hasU ? h2 : 0.0;
+
+  double w0 = bb.x, w1 = bb.y;
+  if (NOISY) {
+    double z0, z1;
+    pmg::normal_pair((uint32_t)t, (uint32_t)(j + (int64_t)L.ny * kg), (uint32_t)op.sweep, ((uint32_t)(op.sweep >> 32) & 0x7fffffffu) | ((uint32_t)c << 31), op.key0, op.key1, tab, z0, z1);
+    const double sqA = uniform(op.sqrtdiag[nyz + 1]), sqB = uniform(op.sqrtdiag[nyz + 2]);
+    const double sq0 = two0 ? sqB : sqA, sq1 = two1 ? sqB : sqA;
+    w0 = z0 * sq0 + bb.x;
+    w1 = z1 * sq1 + bb.y;
+  }
+  // CSR storage order: (k-1) (j-1) (i-1) | (i+1) (j+1) (k+1); absent neighbours contribute an exact +0
+  double s0 = w0, s1 = w1;
+  s0 = s0 + hD * oD.x;
+  s1 = s1 + hD * oD.y;
+  s0 = s0 + hS * oS.x;
+  s1 = s1 + hS * oS.y;
+  s0 = s0 + (hasW0 ? h2 : 0.0) * L0;
+  s1 = s1 + h2 * L1;
+  s0 = s0 + (hasE0 ? h2 : 0.0) * R0;
+  s1 = s1 + (hasE1 ? h2 : 0.0) * R1;
+  s0 = s0 + hN * oN.x;
+  s1 = s1 + hN * oN.y;
+  s0 = s0 + hU * oU.x;
+  s1 = s1 + hU * oU.y;
+
+  double r0, r1;
+  if (OMEGA1) {
+    // (1-omega)*y == 0 exactly; the reference still adds it (src/mc_sor.c:267), which can only change the
+    // sign of an exact zero -- numerically equal
+    r0 = idg0 * s0;
+    r1 = idg1 * s1;
+  } else {
+    const d2 yo2 = ld2(y_own + line);
+    r0           = op.one_minus_omega * yo2.x + idg0 * s0;
+    r1           = op.one_minus_omega * yo2.y + idg1 * s1;
+  }
+  // the slot of a non-existent second point (odd nx) is a pad slot of this line: keep it zero
+  const d2 out = {r0, v1 ? r1 : 0.0};
+  *reinterpret_cast<d2 *>(y_own + line) = out;
+}
+
+// --- first version kept for A/B timing (PMG_GRID_VARIANT=0) ---
 // Sweep of one colour.  Thread = two consecutive points (m = 2t, 2t+1) of colour `c` on one grid line.
 template <bool NOISY, bool OMEGA1>
-__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, const double *__restrict__ b, double *__restrict__ y)
+__global__ __launch_bounds__(256) void grid_color_sweep_v0(pmgk_grid_layout L, pmgk_grid_op op, int c, const double *__restrict__ b, double *__restrict__ y)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -68,7 +177,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
   double w0 = bb.x, w1 = bb.y;
   if (NOISY) {
     double z0, z1;
-    pmg::normal_pair((uint32_t)t, (uint32_t)(j + (int64_t)L.ny * kg), (uint32_t)op.sweep, ((uint32_t)(op.sweep >> 32) & 0x7fffffffu) | ((uint32_t)c << 31), op.key0, op.key1, z0, z1);
+    pmg::normal_pair_ocml((uint32_t)t, (uint32_t)(j + (int64_t)L.ny * kg), (uint32_t)op.sweep, ((uint32_t)(op.sweep >> 32) & 0x7fffffffu) | ((uint32_t)c << 31), op.key0, op.key1, z0, z1);
     w0 = z0 * op.sqrtdiag[nn0] + bb.x;
     w1 = z1 * op.sqrtdiag[nn1] + bb.y;
   }
@@ -194,16 +303,44 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, const double *b, double *y, void *stream)
 {
-  const int  tpl = L->sx / 2; // threads per line
+  const int tpl = L->sx / 2; // threads per line
+  static int variant = -1;
+  if (variant < 0) {
+    const char *e = getenv("PMG_GRID_VARIANT");
+    variant       = e ? atoi(e) : 1;
+  }
+  if (variant == 0) {
+    const dim3 block(64, 4, 1);
+    const dim3 grid((tpl + 63) / 64, (L->ny + 3) / 4, L->nz);
+    hipStream_t s = (hipStream_t)stream;
+    if (op->noisy) {
+      if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_v0<true, true>), grid, block, 0, s, *L, *op, color, b, y);
+      else hipLaunchKernelGGL((grid_color_sweep_v0<true, false>), grid, block, 0, s, *L, *op, color, b, y);
+    } else {
+      if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_v0<false, true>), grid, block, 0, s, *L, *op, color, b, y);
+      else hipLaunchKernelGGL((grid_color_sweep_v0<false, false>), grid, block, 0, s, *L, *op, color, b, y);
+    }
+    return launch_status();
+  }
+  const int nbx = (tpl + 63) / 64, nby = (L->ny + 3) / 4;
+  static int banded_env = -1;
+  if (banded_env < 0) {
+    const char *e = getenv("PMG_GRID_BANDED");
+    banded_env    = e ? atoi(e) : 1;
+  }
+  // XCD-banded dispatch order needs enough line tiles to give every XCD a band
+  const int  bandw = (banded_env && nby >= 16) ? (nby + 7) / 8 : 0;
   const dim3 block(64, 4, 1);
-  const dim3 grid((tpl + 63) / 64, (L->ny + 3) / 4, L->nz);
-  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, L->nz);
+  hipStream_t   s  = (hipStream_t)stream;
+  const double *bo = b + (int64_t)color * L->cs, *yo = y + (int64_t)(1 - color) * L->cs;
+  double       *ys = y + (int64_t)color * L->cs;
   if (op->noisy) {
-    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true>), grid, block, 0, s, *L, *op, color, b, y);
-    else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false>), grid, block, 0, s, *L, *op, color, b, y);
+    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, bo, yo, ys);
+    else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, bo, yo, ys);
   } else {
-    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true>), grid, block, 0, s, *L, *op, color, b, y);
-    else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false>), grid, block, 0, s, *L, *op, color, b, y);
+    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, bo, yo, ys);
+    else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, bo, yo, ys);
   }
   return launch_status();
 }
