@@ -31,6 +31,24 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def measured_traffic(n: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same command
+    (profiles/*_summary.json, written by tools/profile_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 FETCH_SIZE x2 correction calibrated in-run).  None if no summary for this grid size is committed."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*_summary.json")):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        if d.get("n") != n:
+            continue
+        for k in d["kernels"]:
+            if "grid_color_sweep_kernel<true, true>" in k["kernel"] and k.get("hbm_bytes_per_launch"):
+                best = (k["hbm_bytes_per_launch"], f.name)
+    return best
+
+
 def cpu_baseline(nsub: int = 256, nfull: int = 512, samples: int = 8) -> dict:
     """Serial reference path (one colour = lexicographic Gauss-Seidel, reference src/mc_sor.c:397-410,256-271;
     noise per reference src/parmgmc.c:99-110; RHS per src/pc_mcgibbs.c:119-128) on an nsub^3 sub-grid, 1 core,
@@ -124,6 +142,7 @@ def main() -> None:
         t_launch = dev_ms * 1e-3 / launches
         alg_bytes_per_launch = (24 if args.omega == 1.0 else 32) * N_local / 2
         achieved = alg_bytes_per_launch / t_launch / 1e9
+        traffic = measured_traffic(n) if (world == 1 and args.omega == 1.0) else None
         out = {
             "metric": "Gaussian samples/sec on 512^3 3D DMDA (7-pt Laplacian precision, red-black Gibbs sweep = 1 sorgibbs sample)",
             "value": args.steps / dt,
@@ -138,7 +157,7 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{n}^3 DMDA, 7-point shifted Laplacian (kappa=10, h2=1/(n-1)^2), b=1, x0=0, omega={args.omega:g}, forward red-black Gibbs sweep with in-kernel Philox4x32-10 + Box-Muller noise", "unknowns": N_total, "decomposition": f"{world} z-slab(s)", "halo": "none" if world == 1 else "1 plane/colour/neighbour over RCCL send/recv"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "grid_color_sweep_kernel", "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_us": t_launch * 1e6, "note": "24 B/unknown/sweep (read y, write y, read b once; SURVEY 8(d)) x N/2 unknowns per colour launch; duration = HIP-event time of the timed region / launches"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None, "kernel": "grid_color_sweep_kernel", "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_us": t_launch * 1e6, "note": "24 B/unknown/sweep (read y, write y, read b once; SURVEY 8(d)) x N/2 unknowns per colour launch; duration = HIP-event time of the timed region / launches"},
             "finite": finite,
         }
         if world == 1 and not args.no_cpu_baseline:
