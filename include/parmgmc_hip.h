@@ -99,6 +99,17 @@ pmg_status pmg_mcsor_apply(pmg_mcsor mc, const double *b_dev, double *y_dev, voi
 pmg_status pmg_mcsor_sample(pmg_mcsor mc, const double *b_dev, double *y_dev, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
 /* r = b - A y (PCMGResidualDefault / src/pc_gamgmc.c:253-254), natural numbering. */
 pmg_status pmg_mcsor_residual(pmg_mcsor mc, const double *b_dev, const double *y_dev, double *r_dev, void *stream);
+/* The same operations on vectors that already live in the library's colour-partitioned numbering ("layout":
+   length pmg_mcsor_layout_len >= n, pad entries zero), for callers that keep their vectors on the device between
+   calls (the V-cycle does): no permutation pass per call.  pmg_mcsor_get_layout writes, for every matrix row, its
+   position in the layout. */
+pmg_status pmg_mcsor_layout_len(pmg_mcsor mc, int32_t *ld);
+pmg_status pmg_mcsor_get_layout(pmg_mcsor mc, int32_t *pos_of_row_host);
+pmg_status pmg_mcsor_to_layout(pmg_mcsor mc, const double *nat_dev, double *lay_dev, void *stream);
+pmg_status pmg_mcsor_from_layout(pmg_mcsor mc, const double *lay_dev, double *nat_dev, void *stream);
+pmg_status pmg_mcsor_apply_layout(pmg_mcsor mc, const double *b_lay, double *y_lay, void *stream);
+pmg_status pmg_mcsor_sample_layout(pmg_mcsor mc, const double *b_lay, double *y_lay, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+pmg_status pmg_mcsor_residual_layout(pmg_mcsor mc, const double *b_lay, const double *y_lay, double *r_lay, void *stream);
 /* MCSORDestroy (src/mc_sor.c:60-90); *mc = NULL afterwards; NULL handle is a no-op. */
 pmg_status pmg_mcsor_destroy(pmg_mcsor *mc);
 
@@ -119,6 +130,8 @@ pmg_status pmg_grid_get_num_colors(pmg_grid g, int32_t *ncolors);
 pmg_status pmg_grid_get_coloring(pmg_grid g, int32_t *colors_host);
 /* Number of doubles of a colour-partitioned device vector ("cvec") of this grid, ghost planes included. */
 pmg_status pmg_grid_cvec_len(pmg_grid g, int64_t *len);
+/* cvec position of every owned point, DMDA natural order (nx*ny*nz values) */
+pmg_status pmg_grid_get_layout(pmg_grid g, int64_t *pos_of_point_host);
 /* natural (DMDA global vector of the owned planes, i fastest) <-> cvec */
 pmg_status pmg_grid_to_cvec(pmg_grid g, const double *nat_dev, double *cvec_dev, void *stream);
 pmg_status pmg_grid_from_cvec(pmg_grid g, const double *cvec_dev, double *nat_dev, void *stream);
@@ -142,6 +155,55 @@ pmg_status pmg_grid_halo_plane(pmg_grid g, int color, int side, int64_t *owned_o
 /* Sample loop on natural-order vectors: converts in once, runs `its` sweeps, converts out once. */
 pmg_status pmg_grid_sample(pmg_grid g, const double *b_nat_dev, double *y_nat_dev, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
 pmg_status pmg_grid_destroy(pmg_grid *g);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Exact coarse sampler: replaces PCCHOLSAMPLER's dense path (src/pc_chols.c:174-194, :220-291)             */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef struct pmg_chol_s *pmg_chol;
+/* PCSetUp_CholSampler dense branch: MatConvert to dense + potrf('L').  Host CSR of an SPD matrix; returns
+   PMG_ERR_MAT_CH_ZRPVT naming the failing leading minor like src/pc_chols.c:190.  Synchronous. */
+pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host, pmg_chol *ch);
+/* the lower factor L, column-major n*n on the host (upper part zero) */
+pmg_status pmg_chol_get_factor(pmg_chol ch, double *L_colmajor_host);
+/* PCApply_CholSampler (src/pc_chols.c:262-291): y = L^-T (L^-1 b + xi), xi = row-stream normals of
+   (seed, counter); noisy == 0 drops xi (plain solve y = A^-1 b). */
+pmg_status pmg_chol_sample(pmg_chol ch, const double *b_dev, double *y_dev, int noisy, uint64_t seed, uint64_t counter, void *stream);
+pmg_status pmg_chol_destroy(pmg_chol *ch);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Multigrid Monte Carlo on a DMDA hierarchy: replaces PCGAMGMC with -pc_gamgmc_mg_type mg                  */
+/* (src/pc_gamgmc.c) and the PCMG V-cycle it drives                                                        */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef struct pmg_mgmc_s *pmg_mgmc;
+/* Sample callback, the analogue of PetscErrorCode (*cb)(PetscInt it, Vec y, void *ctx) set with
+   PCSetSampleCallback (src/parmgmc.c:146-151): called on the host after sample `it` has been ENQUEUED on the
+   stream, with the sample in DMDA natural order on the device (valid in stream order).  Non-zero return aborts
+   the loop and is returned by pmg_mgmc_sample. */
+typedef int (*pmg_sample_callback)(int32_t it, const double *y_nat_dev, int32_t n, void *ctx);
+/* `levels` grids, the finest nx*ny*nz with the operator of MatAssembleShiftedLaplaceFD (src/problems.c:14-75),
+   each coarser one (n-1)/2+1 points per refined direction (PETSc DMDA coarsening; PMG_ERR_ARG_SIZ if (n-1) is
+   odd).  Defaults = the options PCGAMGMC injects (src/pc_gamgmc.c:299-350): level sampler sorgibbs, 1 sweep
+   before and after, coarse cholsampler, Galerkin coarse operators. */
+pmg_status pmg_mgmc_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa, int32_t levels, pmg_mgmc *mg);
+/* -mg_levels_pc_type sorgibbs (scaled = 0, omega = 1) | mcgibbs (scaled = 1, any omega, any sweep type);
+   its = -mg_levels_ksp_max_it */
+pmg_status pmg_mgmc_set_smoother(pmg_mgmc mg, int scaled, double omega, int sweep_type, int32_t its);
+/* -mg_coarse_pc_type cholsampler (type 0) | Gibbs sweeps with -mg_coarse_ksp_max_it its (type 1) */
+pmg_status pmg_mgmc_set_coarse(pmg_mgmc mg, int type, int32_t its);
+/* keep host copies of the Galerkin operators and interpolations for pmg_mgmc_get_level_matrix */
+pmg_status pmg_mgmc_set_keep_host(pmg_mgmc mg, int keep);
+/* PCSetUp(pg->mg) + PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:145-225, :352-353).  Synchronous. */
+pmg_status pmg_mgmc_setup(pmg_mgmc mg);
+pmg_status pmg_mgmc_get_num_levels(pmg_mgmc mg, int32_t *levels);
+pmg_status pmg_mgmc_get_level_dims(pmg_mgmc mg, int32_t level, int32_t *nx, int32_t *ny, int32_t *nz);
+/* which = 0: Galerkin operator of `level` (< finest); which = 1: interpolation from level-1 to `level`.  CSR in
+   natural numbering; pass NULL arrays to query sizes. */
+pmg_status pmg_mgmc_get_level_matrix(pmg_mgmc mg, int32_t level, int which, int32_t *nrows, int32_t *nnz, int32_t *rowptr_host, int32_t *colidx_host, double *vals_host);
+/* PCApplyRichardson_GAMGMC (src/pc_gamgmc.c:227-264): `its` samples of the chain y <- y + MG(b - A y) (first one
+   y = MG(b) when guesszero != 0), natural-order device vectors.  Sample s = counter0 + it draws its noise from
+   counters [64 s, 64 s + 64) of per-level streams, so a chain can be resumed at any sample. */
+pmg_status pmg_mgmc_sample(pmg_mgmc mg, const double *b_nat_dev, double *y_nat_dev, int32_t its, int guesszero, uint64_t seed, uint64_t counter0, uint64_t *counter_out, pmg_sample_callback cb, void *cbctx, void *stream);
+pmg_status pmg_mgmc_destroy(pmg_mgmc *mg);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* VecSetRandomStandardNormal (src/parmgmc.c:70-116) on the counter-based source: entry r gets the (r&1)    */

@@ -74,6 +74,13 @@ _sig = {
     "pmg_mcsor_apply": (_int, [_vp, _vp, _vp, _vp]),
     "pmg_mcsor_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_mcsor_residual": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pmg_mcsor_layout_len": (_int, [_vp, C.POINTER(_i32)]),
+    "pmg_mcsor_get_layout": (_int, [_vp, _vp]),
+    "pmg_mcsor_to_layout": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_mcsor_from_layout": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_mcsor_apply_layout": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_mcsor_sample_layout": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
+    "pmg_mcsor_residual_layout": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "pmg_mcsor_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_grid_create": (_int, [_i32, _i32, _i32, _i32, _i32, _dbl, C.POINTER(_vp)]),
     "pmg_grid_set_omega": (_int, [_vp, _dbl]),
@@ -82,6 +89,7 @@ _sig = {
     "pmg_grid_get_num_colors": (_int, [_vp, C.POINTER(_i32)]),
     "pmg_grid_get_coloring": (_int, [_vp, _vp]),
     "pmg_grid_cvec_len": (_int, [_vp, C.POINTER(_i64)]),
+    "pmg_grid_get_layout": (_int, [_vp, _vp]),
     "pmg_grid_to_cvec": (_int, [_vp, _vp, _vp, _vp]),
     "pmg_grid_from_cvec": (_int, [_vp, _vp, _vp, _vp]),
     "pmg_grid_apply": (_int, [_vp, _vp, _vp, _vp]),
@@ -92,11 +100,28 @@ _sig = {
     "pmg_grid_halo_plane": (_int, [_vp, _int, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "pmg_grid_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_grid_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_chol_create_csr": (_int, [_i32, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pmg_chol_get_factor": (_int, [_vp, _vp]),
+    "pmg_chol_sample": (_int, [_vp, _vp, _vp, _int, _u64, _u64, _vp]),
+    "pmg_chol_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_mgmc_create_dmda": (_int, [_i32, _i32, _i32, _dbl, _i32, C.POINTER(_vp)]),
+    "pmg_mgmc_set_smoother": (_int, [_vp, _int, _dbl, _int, _i32]),
+    "pmg_mgmc_set_coarse": (_int, [_vp, _int, _i32]),
+    "pmg_mgmc_set_keep_host": (_int, [_vp, _int]),
+    "pmg_mgmc_setup": (_int, [_vp]),
+    "pmg_mgmc_get_num_levels": (_int, [_vp, C.POINTER(_i32)]),
+    "pmg_mgmc_get_level_dims": (_int, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "pmg_mgmc_get_level_matrix": (_int, [_vp, _i32, _int, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _vp]),
+    "pmg_mgmc_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp, _vp, _vp]),
+    "pmg_mgmc_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_vec_set_random_standard_normal": (_int, [_i64, _vp, _u64, _u64, _vp]),
 }
 for _name, (_res, _args) in _sig.items():
     _f = getattr(lib, _name)
     _f.restype, _f.argtypes = _res, _args
+
+
+SAMPLE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p)
 
 
 def check(status: int) -> None:

@@ -97,6 +97,17 @@ __global__ __launch_bounds__(256) void csr_spmv_kernel(int32_t nrows, const int3
   y[r] = beta == 0.0 ? alpha * sum : alpha * sum + beta * y[r];
 }
 
+template <bool ACC>
+__global__ __launch_bounds__(256) void csr_spmv_rows_kernel(int32_t nrows, const int32_t *__restrict__ rowpos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  double sum = 0.0;
+  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) sum = sum + vals[k] * x[colidx[k]];
+  const int o = rowpos[r];
+  y[o]        = ACC ? y[o] + sum : sum;
+}
+
 __global__ void axpy_kernel(int64_t n, double alpha, const double *__restrict__ x, double *__restrict__ y)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,6 +166,15 @@ extern "C" int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t
 {
   if (nrows <= 0) return 0;
   hipLaunchKernelGGL(csr_spmv_kernel, dim3((nrows + 255) / 256), dim3(256), 0, (hipStream_t)stream, nrows, rowptr, colidx, vals, alpha, x, beta, y);
+  return launch_status();
+}
+
+extern "C" int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, void *stream)
+{
+  if (nrows <= 0) return 0;
+  const dim3 grid((nrows + 255) / 256), block(256);
+  if (accumulate) hipLaunchKernelGGL((csr_spmv_rows_kernel<true>), grid, block, 0, (hipStream_t)stream, nrows, rowpos, rowptr, colidx, vals, x, y);
+  else hipLaunchKernelGGL((csr_spmv_rows_kernel<false>), grid, block, 0, (hipStream_t)stream, nrows, rowpos, rowptr, colidx, vals, x, y);
   return launch_status();
 }
 

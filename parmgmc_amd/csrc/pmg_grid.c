@@ -114,6 +114,19 @@ pmg_status pmg_grid_cvec_len(pmg_grid g, int64_t *len)
   return PMG_SUCCESS;
 }
 
+/* cvec position of every owned point, in DMDA natural order (i fastest) */
+pmg_status pmg_grid_get_layout(pmg_grid g, int64_t *pos_of_point)
+{
+  PMG_CHECK(g && pos_of_point, PMG_ERR_ARG_NULL, "null argument");
+  for (int k = 0; k < g->L.nz; ++k)
+    for (int j = 0; j < g->L.ny; ++j)
+      for (int i = 0; i < g->L.nx; ++i) {
+        const int c = (i + j + k + g->L.kz0) & 1;
+        pos_of_point[i + (int64_t)g->L.nx * (j + (int64_t)g->L.ny * k)] = (int64_t)c * g->L.cs + (int64_t)(k + 1) * g->L.sp + (int64_t)j * g->L.sx + (i >> 1);
+      }
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_grid_to_cvec(pmg_grid g, const double *nat, double *cvec, void *stream)
 {
   PMG_CHECK(g && nat && cvec, PMG_ERR_ARG_NULL, "null argument");

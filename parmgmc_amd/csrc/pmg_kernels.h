@@ -71,6 +71,11 @@ int pmgk_permute_out(int32_t ld, const int32_t *orig, const double *perm, double
 
 /* generic CSR product on device arrays: y = alpha*A x + beta*y  (rows in any layout) */
 int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, double alpha, const double *x, double beta, double *y, void *stream);
+/* y[rowpos[r]] (+)= alpha * sum_k vals[k] x[colidx[k]] over the rows of a CSR block whose output positions are
+   given explicitly (transfer operators between level layouts); accumulate != 0 adds to y */
+int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, void *stream);
+/* triangular matrix-vector products of the coarse exact sampler (row-major n x n, lower or upper part) */
+int pmgk_tri_gemv(int32_t n, int upper, const double *M, const double *x, const double *add, double *out, void *stream);
 int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);
 int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream);
 

@@ -426,6 +426,81 @@ pmg_status pmg_mcsor_residual(pmg_mcsor mc, const double *b, const double *y, do
   return PMG_SUCCESS;
 }
 
+/* ---- entry points on vectors that already live in the colour-partitioned numbering ("layout") ---------- */
+
+pmg_status pmg_mcsor_layout_len(pmg_mcsor mc, int32_t *ld)
+{
+  PMG_CHECK(mc && ld, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(mc->is_setup, PMG_ERR_ARG_WRONGSTATE, "call pmg_mcsor_setup first");
+  *ld = mc->S.ld;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mcsor_get_layout(pmg_mcsor mc, int32_t *pos_of_row)
+{
+  PMG_CHECK(mc && pos_of_row, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(mc->is_setup, PMG_ERR_ARG_WRONGSTATE, "call pmg_mcsor_setup first");
+  for (int32_t p = 0; p < mc->S.ld; ++p)
+    if (mc->orig_host[p] >= 0) pos_of_row[mc->orig_host[p]] = p;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mcsor_to_layout(pmg_mcsor mc, const double *nat, double *lay, void *stream)
+{
+  PMG_CHECK(mc && nat && lay, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(mc->is_setup, PMG_ERR_ARG_WRONGSTATE, "call pmg_mcsor_setup first");
+  PMG_KERNEL(pmgk_permute_in(mc->S.ld, mc->S.orig, nat, lay, stream));
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mcsor_from_layout(pmg_mcsor mc, const double *lay, double *nat, void *stream)
+{
+  PMG_CHECK(mc && nat && lay, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(mc->is_setup, PMG_ERR_ARG_WRONGSTATE, "call pmg_mcsor_setup first");
+  PMG_KERNEL(pmgk_permute_out(mc->S.ld, mc->S.orig, lay, nat, stream));
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mcsor_apply_layout(pmg_mcsor mc, const double *b_lay, double *y_lay, void *stream)
+{
+  PMG_CHECK(mc && b_lay && y_lay, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CALL(mcsor_ready(mc));
+  if (mc->type == PMG_SOR_SYMMETRIC_SWEEP) {
+    PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_FORWARD_SWEEP, 0, 0, 0, 0, b_lay, y_lay, stream));
+    PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_BACKWARD_SWEEP, 0, 0, 0, 0, b_lay, y_lay, stream));
+  } else {
+    PMG_CALL(mcsor_one_sweep(mc, mc->type, 0, 0, 0, 0, b_lay, y_lay, stream));
+  }
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mcsor_sample_layout(pmg_mcsor mc, const double *b_lay, double *y_lay, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+{
+  PMG_CHECK(mc && b_lay && y_lay, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(its >= 0, PMG_ERR_ARG_OUTOFRANGE, "its = %d", its);
+  PMG_CHECK(scaled || mc->omega == 1.0, PMG_ERR_SUP, "the unscaled (sorgibbs) noise requires omega = 1 (src/pc_sorgibbs.c:94)");
+  PMG_CALL(mcsor_ready(mc));
+  uint64_t ctr = counter0;
+  for (int it = 0; it < its; ++it) {
+    if (mc->type == PMG_SOR_SYMMETRIC_SWEEP) {
+      PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_FORWARD_SWEEP, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
+      PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_BACKWARD_SWEEP, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
+    } else {
+      PMG_CALL(mcsor_one_sweep(mc, mc->type, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
+    }
+  }
+  if (counter_out) *counter_out = ctr;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mcsor_residual_layout(pmg_mcsor mc, const double *b_lay, const double *y_lay, double *r_lay, void *stream)
+{
+  PMG_CHECK(mc && b_lay && y_lay && r_lay, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CALL(mcsor_ready(mc));
+  PMG_KERNEL(pmgk_sell_residual(&mc->S, b_lay, y_lay, r_lay, stream));
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_mcsor_destroy(pmg_mcsor *mc)
 {
   if (!mc || !*mc) return PMG_SUCCESS;

@@ -1,0 +1,579 @@
+/* Multigrid Monte Carlo sampler on a DMDA hierarchy -- host side (C11).
+ *
+ * Mirrors PCGAMGMC with `-pc_gamgmc_mg_type mg` (reference src/pc_gamgmc.c) together with the part of PETSc's PCMG
+ * it drives (third party, restated from PETSc's documented semantics -- parity unpinned by any reference fixture):
+ *   - hierarchy: vertex-centred 2:1 coarsening nc = (nf-1)/2 + 1, Q1 (bi/tri-linear) interpolation as DMDA's
+ *     DMCreateInterpolation builds it, restriction R = P^T, Galerkin coarse operators A_c = P^T A P
+ *     (-pc_mg_galerkin both, injected at src/pc_gamgmc.c:345-349);
+ *   - level "smoothers" = Gibbs samplers (default sorgibbs, KSPRICHARDSON, max_it 1: src/pc_gamgmc.c:318-334),
+ *     coarse "solver" = exact Cholesky sampler (src/pc_gamgmc.c:336-342) or Gibbs sweeps (examples/ex1.c:35);
+ *   - one V-cycle: pre-smooth, r = b - A x, b_c = P^T r, recurse from x_c = 0, x += P x_c, post-smooth;
+ *   - the outer chain in correction form, PCApplyRichardson_GAMGMC (src/pc_gamgmc.c:227-264):
+ *     first iteration from a zero guess y = MG(b), afterwards w = b - A y, y += MG(w); callback per sample.
+ * The finest level is the matrix-free red-black grid operator (pmg_grid); coarser levels are 9/27-point Galerkin
+ * matrices swept with the sliced-ELL kernel under the 4/8-colour parity colouring (red-black is not a valid
+ * colouring of a 27-point stencil); transfers are CSR products between the levels' storage layouts.
+ */
+#include "pmg_internal.h"
+#include <math.h>
+
+typedef struct {
+  int32_t  nr, nc;
+  int32_t *rp, *ci;
+  double  *v;
+} hcsr;
+
+static void hcsr_free(hcsr *m)
+{
+  free(m->rp);
+  free(m->ci);
+  free(m->v);
+  memset(m, 0, sizeof *m);
+}
+
+typedef struct {
+  int32_t   nx, ny, nz, n;
+  int       is_grid;
+  pmg_grid  g;
+  pmg_mcsor mc;
+  int64_t   ld;
+  double   *b, *x, *r;
+  /* transfers to the next coarser level, in layout numbering on the device */
+  int32_t  P_nrows, R_nrows;
+  int32_t *P_rowpos, *P_rowptr, *P_col, *R_rowpos, *R_rowptr, *R_col;
+  double  *P_val, *R_val;
+  /* optional host copies (natural numbering) for inspection */
+  hcsr A_host, P_host;
+} mg_level;
+
+struct pmg_mgmc_s {
+  int       nlevels;
+  mg_level *lv; /* lv[0] = coarsest */
+  double    kappa, omega;
+  int       nu, scaled, sweep_type;
+  int       coarse_type, coarse_its; /* 0 = cholsampler, 1 = Gibbs sweeps */
+  int       keep_host, is_setup;
+  pmg_chol  chol;
+  double   *y_lay, *b_lay;
+};
+
+#define MG_DRAWS_PER_SAMPLE 64u
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* host sparse tools                                                                                    */
+/* ---------------------------------------------------------------------------------------------------- */
+
+/* Q1 interpolation from the (ncx,ncy,ncz) grid to the (nfx,nfy,nfz) grid, natural ordering, columns ascending.
+   Per direction: fine 2I coincides with coarse I (weight 1), fine 2I+1 lies midway (1/2, 1/2); a direction with
+   one point is not coarsened. */
+static pmg_status q1_interp(const int32_t nf[3], const int32_t nc[3], hcsr *P)
+{
+  const int64_t nrow = (int64_t)nf[0] * nf[1] * nf[2];
+  P->nr              = (int32_t)nrow;
+  P->nc              = nc[0] * nc[1] * nc[2];
+  P->rp              = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nrow + 1));
+  /* count */
+  int64_t nnz = 0;
+  int64_t cnt[3][2]; /* per direction: number of fine points with 1 / 2 contributions */
+  for (int d = 0; d < 3; ++d) {
+    if (nf[d] == nc[d]) {
+      cnt[d][0] = nf[d];
+      cnt[d][1] = 0;
+    } else {
+      cnt[d][0] = (nf[d] + 1) / 2;
+      cnt[d][1] = nf[d] / 2;
+    }
+  }
+  nnz   = (cnt[0][0] + 2 * cnt[0][1]) * (cnt[1][0] + 2 * cnt[1][1]) * (cnt[2][0] + 2 * cnt[2][1]);
+  P->ci = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+  P->v  = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+  PMG_CHECK(P->rp && P->ci && P->v, PMG_ERR_MEM, "out of host memory for the interpolation");
+  int64_t p = 0;
+  for (int k = 0; k < nf[2]; ++k)
+    for (int j = 0; j < nf[1]; ++j)
+      for (int i = 0; i < nf[0]; ++i) {
+        const int f[3] = {i, j, k};
+        int       c0[3], m[3];
+        double    w[3][2];
+        for (int d = 0; d < 3; ++d) {
+          if (nf[d] == nc[d]) { c0[d] = f[d]; m[d] = 1; w[d][0] = 1.0; }
+          else if ((f[d] & 1) == 0) { c0[d] = f[d] / 2; m[d] = 1; w[d][0] = 1.0; }
+          else { c0[d] = f[d] / 2; m[d] = 2; w[d][0] = 0.5; w[d][1] = 0.5; }
+        }
+        P->rp[i + (int64_t)nf[0] * (j + (int64_t)nf[1] * k)] = (int32_t)p;
+        for (int c = 0; c < m[2]; ++c)
+          for (int bq = 0; bq < m[1]; ++bq)
+            for (int a = 0; a < m[0]; ++a) {
+              P->ci[p] = (c0[0] + a) + nc[0] * ((c0[1] + bq) + nc[1] * (c0[2] + c));
+              P->v[p]  = w[0][a] * w[1][bq] * w[2][c];
+              ++p;
+            }
+      }
+  P->rp[nrow] = (int32_t)p;
+  return PMG_SUCCESS;
+}
+
+static pmg_status hcsr_transpose(const hcsr *A, hcsr *T)
+{
+  const int32_t nnz = A->rp[A->nr];
+  T->nr             = A->nc;
+  T->nc             = A->nr;
+  T->rp             = (int32_t *)calloc((size_t)T->nr + 1, sizeof(int32_t));
+  T->ci             = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+  T->v              = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+  PMG_CHECK(T->rp && T->ci && T->v, PMG_ERR_MEM, "out of host memory");
+  for (int32_t k = 0; k < nnz; ++k) T->rp[A->ci[k] + 1]++;
+  for (int32_t r = 0; r < T->nr; ++r) T->rp[r + 1] += T->rp[r];
+  int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)(T->nr > 0 ? T->nr : 1));
+  PMG_CHECK(fill, PMG_ERR_MEM, "out of host memory");
+  memcpy(fill, T->rp, sizeof(int32_t) * (size_t)T->nr);
+  for (int32_t r = 0; r < A->nr; ++r)
+    for (int32_t k = A->rp[r]; k < A->rp[r + 1]; ++k) {
+      const int32_t q = fill[A->ci[k]]++;
+      T->ci[q]        = r;
+      T->v[q]         = A->v[k];
+    }
+  free(fill);
+  return PMG_SUCCESS;
+}
+
+/* row generator: either a stored CSR or the matrix-free 7-point operator of src/problems.c:14-75 */
+typedef struct {
+  const hcsr *A;
+  int32_t     nx, ny, nz;
+  double      kappa, h2, diag[8];
+} rowsrc;
+
+static int rowsrc_get(const rowsrc *s, int32_t row, int32_t *cols, double *vals)
+{
+  if (s->A) {
+    const int32_t a = s->A->rp[row], n = s->A->rp[row + 1] - a;
+    memcpy(cols, s->A->ci + a, sizeof(int32_t) * (size_t)n);
+    memcpy(vals, s->A->v + a, sizeof(double) * (size_t)n);
+    return n;
+  }
+  const int32_t i = row % s->nx, j = (row / s->nx) % s->ny, k = row / (s->nx * s->ny);
+  int           n = 0, nn = (k > 0) + (j > 0) + (i > 0) + (i < s->nx - 1) + (j < s->ny - 1) + (k < s->nz - 1);
+  if (k > 0) { cols[n] = row - s->nx * s->ny; vals[n++] = -s->h2; }
+  if (j > 0) { cols[n] = row - s->nx; vals[n++] = -s->h2; }
+  if (i > 0) { cols[n] = row - 1; vals[n++] = -s->h2; }
+  cols[n] = row; vals[n++] = s->diag[nn];
+  if (i < s->nx - 1) { cols[n] = row + 1; vals[n++] = -s->h2; }
+  if (j < s->ny - 1) { cols[n] = row + s->nx; vals[n++] = -s->h2; }
+  if (k < s->nz - 1) { cols[n] = row + s->nx * s->ny; vals[n++] = -s->h2; }
+  return n;
+}
+
+static int cmp_i32(const void *a, const void *b) { return (*(const int32_t *)a > *(const int32_t *)b) - (*(const int32_t *)a < *(const int32_t *)b); }
+
+/* C = P^T A P, fused: for coarse row I, for i in R_I, for (j,a) in A_i, for (J,p) in P_j: C[I,J] += r a p */
+static pmg_status galerkin_rap(const rowsrc *A, int maxrow, const hcsr *P, const hcsr *R, hcsr *Cm)
+{
+  const int32_t nc = P->nc;
+  Cm->nr = Cm->nc = nc;
+  Cm->rp          = (int32_t *)calloc((size_t)nc + 1, sizeof(int32_t));
+  size_t   cap    = (size_t)nc * 32 + 64;
+  Cm->ci          = (int32_t *)malloc(sizeof(int32_t) * cap);
+  Cm->v           = (double *)malloc(sizeof(double) * cap);
+  double  *acc    = (double *)calloc((size_t)nc, sizeof(double));
+  int32_t *mark   = (int32_t *)malloc(sizeof(int32_t) * (size_t)nc);
+  int32_t *list   = (int32_t *)malloc(sizeof(int32_t) * (size_t)nc);
+  int32_t *cols   = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxrow);
+  double  *vals   = (double *)malloc(sizeof(double) * (size_t)maxrow);
+  PMG_CHECK(Cm->rp && Cm->ci && Cm->v && acc && mark && list && cols && vals, PMG_ERR_MEM, "out of host memory in the Galerkin product");
+  for (int32_t q = 0; q < nc; ++q) mark[q] = -1;
+  size_t nnz = 0;
+  for (int32_t I = 0; I < nc; ++I) {
+    int32_t nl = 0;
+    for (int32_t kr = R->rp[I]; kr < R->rp[I + 1]; ++kr) {
+      const int32_t i  = R->ci[kr];
+      const double  rv = R->v[kr];
+      const int     na = rowsrc_get(A, i, cols, vals);
+      for (int ka = 0; ka < na; ++ka) {
+        const int32_t j  = cols[ka];
+        const double  ra = rv * vals[ka];
+        for (int32_t kp = P->rp[j]; kp < P->rp[j + 1]; ++kp) {
+          const int32_t J = P->ci[kp];
+          if (mark[J] != I) {
+            mark[J]    = I;
+            list[nl++] = J;
+            acc[J]     = 0.0;
+          }
+          acc[J] += ra * P->v[kp];
+        }
+      }
+    }
+    qsort(list, (size_t)nl, sizeof(int32_t), cmp_i32);
+    if (nnz + (size_t)nl > cap) {
+      cap     = (cap + (size_t)nl) * 2;
+      Cm->ci  = (int32_t *)realloc(Cm->ci, sizeof(int32_t) * cap);
+      Cm->v   = (double *)realloc(Cm->v, sizeof(double) * cap);
+      PMG_CHECK(Cm->ci && Cm->v, PMG_ERR_MEM, "out of host memory in the Galerkin product");
+    }
+    for (int32_t q = 0; q < nl; ++q) {
+      Cm->ci[nnz] = list[q];
+      Cm->v[nnz]  = acc[list[q]];
+      ++nnz;
+    }
+    PMG_CHECK(nnz < 2147483647u, PMG_ERR_ARG_OUTOFRANGE, "coarse operator exceeds 32-bit nonzero count");
+    Cm->rp[I + 1] = (int32_t)nnz;
+  }
+  free(acc);
+  free(mark);
+  free(list);
+  free(cols);
+  free(vals);
+  return PMG_SUCCESS;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* public                                                                                               */
+/* ---------------------------------------------------------------------------------------------------- */
+
+pmg_status pmg_mgmc_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa, int32_t levels, pmg_mgmc *out)
+{
+  PMG_CHECK(out, PMG_ERR_ARG_NULL, "null output handle");
+  *out = NULL;
+  PMG_CHECK(levels >= 2, PMG_ERR_ARG_OUTOFRANGE, "need at least 2 levels (got %d)", levels);
+  PMG_CHECK(nx >= 3 && ny >= 1 && nz >= 1, PMG_ERR_ARG_OUTOFRANGE, "grid %d x %d x %d", nx, ny, nz);
+  pmg_mgmc h = (pmg_mgmc)calloc(1, sizeof *h);
+  PMG_CHECK(h, PMG_ERR_MEM, "out of host memory");
+  h->lv = (mg_level *)calloc((size_t)levels, sizeof(mg_level));
+  if (!h->lv) {
+    free(h);
+    PMG_FAIL(PMG_ERR_MEM, "out of host memory");
+  }
+  h->nlevels    = levels;
+  h->kappa      = kappa;
+  h->omega      = 1.0;
+  h->nu         = 1;                      /* -mg_levels_ksp_max_it 1, src/pc_gamgmc.c:324-328 */
+  h->scaled     = 0;                      /* -mg_levels_pc_type sorgibbs, :330-334            */
+  h->sweep_type = PMG_SOR_FORWARD_SWEEP;
+  h->coarse_type = 0;                     /* -mg_coarse_pc_type cholsampler, :336-342         */
+  h->coarse_its  = 1;
+  int32_t d[3]   = {nx, ny, nz};
+  for (int l = levels - 1; l >= 0; --l) {
+    h->lv[l].nx = d[0];
+    h->lv[l].ny = d[1];
+    h->lv[l].nz = d[2];
+    h->lv[l].n  = d[0] * d[1] * d[2];
+    if (l > 0)
+      for (int q = 0; q < 3; ++q)
+        if (d[q] > 1) {
+          if ((d[q] - 1) % 2 != 0 || d[q] < 3) {
+            const int32_t bad = d[q];
+            free(h->lv);
+            free(h);
+            PMG_FAIL(PMG_ERR_ARG_SIZ, "level %d has %d points in direction %d: vertex-centred 2:1 coarsening needs (n-1) even and n >= 3 on every refined level (use 2^k+1 points)", l, bad, q);
+          }
+          d[q] = (d[q] - 1) / 2 + 1;
+        }
+  }
+  *out = h;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_set_smoother(pmg_mgmc h, int scaled, double omega, int sweep_type, int32_t its)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(!h->is_setup, PMG_ERR_ARG_WRONGSTATE, "set the smoother before pmg_mgmc_setup");
+  PMG_CHECK(pmg_sweep_type_ok(sweep_type), PMG_ERR_SUP, "Only forward, backward and symmetric sweep supported");
+  PMG_CHECK(scaled || omega == 1.0, PMG_ERR_SUP, "sorgibbs smoothing requires omega = 1");
+  PMG_CHECK(its >= 1 && (uint32_t)its * 4u <= MG_DRAWS_PER_SAMPLE, PMG_ERR_ARG_OUTOFRANGE, "smoothing iterations %d", its);
+  h->scaled     = scaled;
+  h->omega      = omega;
+  h->sweep_type = sweep_type;
+  h->nu         = its;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_set_coarse(pmg_mgmc h, int type, int32_t its)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(!h->is_setup, PMG_ERR_ARG_WRONGSTATE, "set the coarse sampler before pmg_mgmc_setup");
+  PMG_CHECK(type == 0 || type == 1, PMG_ERR_ARG_OUTOFRANGE, "coarse sampler type %d", type);
+  PMG_CHECK(its >= 1 && (uint32_t)its * 2u <= MG_DRAWS_PER_SAMPLE, PMG_ERR_ARG_OUTOFRANGE, "coarse iterations %d", its);
+  h->coarse_type = type;
+  h->coarse_its  = its;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_set_keep_host(pmg_mgmc h, int keep)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  h->keep_host = keep;
+  return PMG_SUCCESS;
+}
+
+static pmg_status upload_transfer(const hcsr *M, const int32_t *rowpos_of, const int32_t *colpos_of, int32_t **rowpos, int32_t **rowptr, int32_t **col, double **val)
+{
+  const int32_t nnz = M->rp[M->nr];
+  int32_t      *rp  = (int32_t *)malloc(sizeof(int32_t) * (size_t)(M->nr > 0 ? M->nr : 1));
+  int32_t      *cc  = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+  PMG_CHECK(rp && cc, PMG_ERR_MEM, "out of host memory");
+  for (int32_t r = 0; r < M->nr; ++r) rp[r] = rowpos_of[r];
+  for (int32_t k = 0; k < nnz; ++k) cc[k] = colpos_of[M->ci[k]];
+  pmg_status st = pmg_dev_upload((void **)rowpos, rp, sizeof(int32_t) * (size_t)M->nr);
+  if (!st) st = pmg_dev_upload((void **)rowptr, M->rp, sizeof(int32_t) * ((size_t)M->nr + 1));
+  if (!st) st = pmg_dev_upload((void **)col, cc, sizeof(int32_t) * (size_t)nnz);
+  if (!st) st = pmg_dev_upload((void **)val, M->v, sizeof(double) * (size_t)nnz);
+  free(rp);
+  free(cc);
+  return st;
+}
+
+pmg_status pmg_mgmc_setup(pmg_mgmc h)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  if (h->is_setup) return PMG_SUCCESS;
+  const int top = h->nlevels - 1;
+  /* finest level: matrix-free grid operator */
+  mg_level *F = &h->lv[top];
+  F->is_grid  = 1;
+  PMG_CALL(pmg_grid_create(F->nx, F->ny, F->nz, 0, F->nz, h->kappa, &F->g));
+  PMG_CALL(pmg_grid_set_omega(F->g, h->omega));
+  PMG_CALL(pmg_grid_set_sweep_type(F->g, h->sweep_type));
+  PMG_CALL(pmg_grid_cvec_len(F->g, &F->ld));
+  PMG_CHECK(F->ld < 2147483647, PMG_ERR_ARG_OUTOFRANGE, "fine level layout exceeds 32-bit positions");
+
+  int32_t **pos = (int32_t **)calloc((size_t)h->nlevels, sizeof(int32_t *)); /* natural index -> layout position per level */
+  PMG_CHECK(pos, PMG_ERR_MEM, "out of host memory");
+  {
+    int64_t *p64 = (int64_t *)malloc(sizeof(int64_t) * (size_t)F->n);
+    pos[top]     = (int32_t *)malloc(sizeof(int32_t) * (size_t)F->n);
+    PMG_CHECK(p64 && pos[top], PMG_ERR_MEM, "out of host memory");
+    PMG_CALL(pmg_grid_get_layout(F->g, p64));
+    for (int32_t q = 0; q < F->n; ++q) pos[top][q] = (int32_t)p64[q];
+    free(p64);
+  }
+  rowsrc src;
+  memset(&src, 0, sizeof src);
+  src.nx    = F->nx;
+  src.ny    = F->ny;
+  src.nz    = F->nz;
+  src.kappa = h->kappa;
+  src.h2    = 1. / ((F->nx - 1) * (F->nx - 1)); /* src/problems.c:24 */
+  for (int nn = 0; nn < 8; ++nn) {
+    double dgl = h->kappa * h->kappa;
+    for (int q = 0; q < nn; ++q) dgl += src.h2;
+    src.diag[nn] = dgl;
+  }
+  hcsr Aprev;
+  memset(&Aprev, 0, sizeof Aprev);
+  for (int l = top; l >= 1; --l) {
+    mg_level     *U = &h->lv[l], *Cc = &h->lv[l - 1];
+    const int32_t nf[3] = {U->nx, U->ny, U->nz}, ncd[3] = {Cc->nx, Cc->ny, Cc->nz};
+    hcsr          P, R, Ac;
+    memset(&P, 0, sizeof P);
+    memset(&R, 0, sizeof R);
+    memset(&Ac, 0, sizeof Ac);
+    PMG_CALL(q1_interp(nf, ncd, &P));
+    PMG_CALL(hcsr_transpose(&P, &R));
+    rowsrc s = src;
+    if (l < top) s.A = &Aprev;
+    PMG_CALL(galerkin_rap(&s, l == top ? 7 : 64, &P, &R, &Ac));
+    /* coarse level operator object */
+    const int is_coarsest = (l - 1 == 0);
+    pos[l - 1]            = (int32_t *)malloc(sizeof(int32_t) * (size_t)Cc->n);
+    PMG_CHECK(pos[l - 1], PMG_ERR_MEM, "out of host memory");
+    if (!is_coarsest || h->coarse_type == 1) {
+      int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)Cc->n);
+      PMG_CHECK(col, PMG_ERR_MEM, "out of host memory");
+      /* parity colouring (i&1) + 2(j&1) + 4(k&1), compressed to consecutive colours: valid for the 9/27-point box */
+      int present[8] = {0}, remap[8], ncol = 0;
+      for (int32_t k = 0; k < Cc->nz; ++k)
+        for (int32_t j = 0; j < Cc->ny; ++j)
+          for (int32_t i = 0; i < Cc->nx; ++i) present[(i & 1) + 2 * (j & 1) + 4 * (k & 1)] = 1;
+      for (int q = 0; q < 8; ++q) remap[q] = present[q] ? ncol++ : -1;
+      for (int32_t k = 0; k < Cc->nz; ++k)
+        for (int32_t j = 0; j < Cc->ny; ++j)
+          for (int32_t i = 0; i < Cc->nx; ++i) col[i + Cc->nx * (j + Cc->ny * k)] = remap[(i & 1) + 2 * (j & 1) + 4 * (k & 1)];
+      PMG_CALL(pmg_mcsor_create_csr(Cc->n, Ac.rp, Ac.ci, Ac.v, &Cc->mc));
+      PMG_CALL(pmg_mcsor_set_coloring(Cc->mc, PMG_COLORING_USER, col));
+      PMG_CALL(pmg_mcsor_set_omega(Cc->mc, h->omega));
+      PMG_CALL(pmg_mcsor_set_sweep_type(Cc->mc, h->sweep_type));
+      PMG_CALL(pmg_mcsor_setup(Cc->mc));
+      free(col);
+      int32_t ld32;
+      PMG_CALL(pmg_mcsor_layout_len(Cc->mc, &ld32));
+      Cc->ld = ld32;
+      PMG_CALL(pmg_mcsor_get_layout(Cc->mc, pos[l - 1]));
+    } else {
+      Cc->ld = Cc->n;
+      for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q;
+    }
+    if (is_coarsest && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr(Cc->n, Ac.rp, Ac.ci, Ac.v, &h->chol));
+    /* transfers in layout numbering */
+    U->P_nrows = P.nr;
+    U->R_nrows = R.nr;
+    PMG_CALL(upload_transfer(&P, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
+    PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    hcsr_free(&R);
+    if (h->keep_host) U->P_host = P;
+    else hcsr_free(&P);
+    hcsr_free(&Aprev);
+    Aprev = Ac;
+    if (h->keep_host) { /* deep copy for inspection */
+      const int32_t nnz = Ac.rp[Ac.nr];
+      Cc->A_host.nr = Cc->A_host.nc = Ac.nr;
+      Cc->A_host.rp = (int32_t *)malloc(sizeof(int32_t) * ((size_t)Ac.nr + 1));
+      Cc->A_host.ci = (int32_t *)malloc(sizeof(int32_t) * (size_t)nnz);
+      Cc->A_host.v  = (double *)malloc(sizeof(double) * (size_t)nnz);
+      PMG_CHECK(Cc->A_host.rp && Cc->A_host.ci && Cc->A_host.v, PMG_ERR_MEM, "out of host memory");
+      memcpy(Cc->A_host.rp, Ac.rp, sizeof(int32_t) * ((size_t)Ac.nr + 1));
+      memcpy(Cc->A_host.ci, Ac.ci, sizeof(int32_t) * (size_t)nnz);
+      memcpy(Cc->A_host.v, Ac.v, sizeof(double) * (size_t)nnz);
+    }
+  }
+  hcsr_free(&Aprev);
+  for (int l = 0; l < h->nlevels; ++l) {
+    free(pos[l]);
+    mg_level *Lv = &h->lv[l];
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->b, sizeof(double) * (size_t)Lv->ld));
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->x, sizeof(double) * (size_t)Lv->ld));
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->r, sizeof(double) * (size_t)Lv->ld));
+  }
+  free(pos);
+  PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)F->ld));
+  PMG_CALL(pmg_dev_alloc((void **)&h->b_lay, sizeof(double) * (size_t)F->ld));
+  h->is_setup = 1;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_get_num_levels(pmg_mgmc h, int32_t *levels)
+{
+  PMG_CHECK(h && levels, PMG_ERR_ARG_NULL, "null argument");
+  *levels = h->nlevels;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_get_level_dims(pmg_mgmc h, int32_t level, int32_t *nx, int32_t *ny, int32_t *nz)
+{
+  PMG_CHECK(h && nx && ny && nz, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(level >= 0 && level < h->nlevels, PMG_ERR_ARG_OUTOFRANGE, "level %d", level);
+  *nx = h->lv[level].nx;
+  *ny = h->lv[level].ny;
+  *nz = h->lv[level].nz;
+  return PMG_SUCCESS;
+}
+
+/* which = 0: Galerkin operator of `level` (< finest); which = 1: interpolation from level-1 to `level` (>= 1).
+   Call with NULL arrays to query nrows/nnz.  Needs pmg_mgmc_set_keep_host(h, 1) before set-up. */
+pmg_status pmg_mgmc_get_level_matrix(pmg_mgmc h, int32_t level, int which, int32_t *nrows, int32_t *nnz, int32_t *rowptr, int32_t *colidx, double *vals)
+{
+  PMG_CHECK(h && nrows && nnz, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(h->is_setup && h->keep_host, PMG_ERR_ARG_WRONGSTATE, "needs pmg_mgmc_set_keep_host(h,1) and pmg_mgmc_setup");
+  PMG_CHECK(level >= 0 && level < h->nlevels, PMG_ERR_ARG_OUTOFRANGE, "level %d", level);
+  const hcsr *M = which == 0 ? &h->lv[level].A_host : &h->lv[level].P_host;
+  PMG_CHECK(M->rp, PMG_ERR_ARG_OUTOFRANGE, "level %d has no such matrix", level);
+  *nrows = M->nr;
+  *nnz   = M->rp[M->nr];
+  if (rowptr) memcpy(rowptr, M->rp, sizeof(int32_t) * ((size_t)M->nr + 1));
+  if (colidx) memcpy(colidx, M->ci, sizeof(int32_t) * (size_t)*nnz);
+  if (vals) memcpy(vals, M->v, sizeof(double) * (size_t)*nnz);
+  return PMG_SUCCESS;
+}
+
+/* per-level noise seed: levels draw from independent streams */
+static uint64_t level_seed(uint64_t seed, int level) { return seed + 0x9E3779B97F4A7C15ull * (uint64_t)(level + 1); }
+
+static pmg_status mg_smooth(pmg_mgmc h, int l, uint64_t seed, uint64_t *ctr, void *stream)
+{
+  mg_level *Lv = &h->lv[l];
+  if (Lv->is_grid) PMG_CALL(pmg_grid_sample_cvec(Lv->g, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
+  else PMG_CALL(pmg_mcsor_sample_layout(Lv->mc, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
+  return PMG_SUCCESS;
+}
+
+/* one multiplicative V-cycle on lv[top].b -> lv[top].x (x starts at zero on every level) */
+static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, void *stream)
+{
+  const int top = h->nlevels - 1;
+  uint64_t  ctr[64];
+  PMG_CHECK(h->nlevels <= 64, PMG_ERR_ARG_OUTOFRANGE, "too many levels");
+  for (int l = 0; l <= top; ++l) ctr[l] = sample * MG_DRAWS_PER_SAMPLE;
+  for (int l = top; l >= 1; --l) {
+    mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
+    PMG_HIP(hipMemsetAsync(Lv->x, 0, sizeof(double) * (size_t)Lv->ld, (hipStream_t)stream));
+    PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
+    if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
+    else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
+    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, Lv->r, Cc->b, 0, stream)); /* MatRestrict */
+  }
+  {
+    mg_level *C0 = &h->lv[0];
+    if (h->coarse_type == 0) {
+      PMG_CALL(pmg_chol_sample(h->chol, C0->b, C0->x, 1, level_seed(seed, 0), ctr[0], stream));
+    } else {
+      PMG_HIP(hipMemsetAsync(C0->x, 0, sizeof(double) * (size_t)C0->ld, (hipStream_t)stream));
+      PMG_CALL(pmg_mcsor_sample_layout(C0->mc, C0->b, C0->x, h->coarse_its, h->scaled, level_seed(seed, 0), ctr[0], &ctr[0], stream));
+    }
+  }
+  for (int l = 1; l <= top; ++l) {
+    mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
+    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, Cc->x, Lv->x, 1, stream)); /* MatInterpolateAdd */
+    PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
+  }
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32_t its, int guesszero, uint64_t seed, uint64_t counter0, uint64_t *counter_out, pmg_sample_callback cb, void *cbctx, void *stream)
+{
+  PMG_CHECK(h && b_nat && y_nat, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(h->is_setup, PMG_ERR_ARG_WRONGSTATE, "call pmg_mgmc_setup first");
+  PMG_CHECK(its >= 0, PMG_ERR_ARG_OUTOFRANGE, "its = %d", its);
+  mg_level    *F     = &h->lv[h->nlevels - 1];
+  const size_t bytes = sizeof(double) * (size_t)F->ld;
+  PMG_CALL(pmg_grid_to_cvec(F->g, b_nat, h->b_lay, stream));
+  PMG_CALL(pmg_grid_to_cvec(F->g, y_nat, h->y_lay, stream));
+  for (int32_t it = 0; it < its; ++it) {
+    if (it == 0 && guesszero) { /* y = MG(b), src/pc_gamgmc.c:243-246 */
+      PMG_HIP(hipMemcpyAsync(F->b, h->b_lay, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+      PMG_CALL(mg_vcycle(h, seed, counter0 + (uint64_t)it, stream));
+      PMG_HIP(hipMemcpyAsync(h->y_lay, F->x, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    } else { /* w = b - A y; work = MG(w); y += work, src/pc_gamgmc.c:253-256 */
+      PMG_CALL(pmg_grid_residual_cvec(F->g, h->b_lay, h->y_lay, F->b, stream));
+      PMG_CALL(mg_vcycle(h, seed, counter0 + (uint64_t)it, stream));
+      PMG_KERNEL(pmgk_axpy(F->ld, 1.0, F->x, h->y_lay, stream));
+    }
+    if (cb) { /* pg->scb(it, y, ctx), src/pc_gamgmc.c:258 */
+      PMG_CALL(pmg_grid_from_cvec(F->g, h->y_lay, y_nat, stream));
+      const int rc = cb(it, y_nat, F->n, cbctx);
+      PMG_CHECK(rc == 0, rc, "sample callback returned %d", rc);
+    }
+  }
+  PMG_CALL(pmg_grid_from_cvec(F->g, h->y_lay, y_nat, stream));
+  if (counter_out) *counter_out = counter0 + (uint64_t)its;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
+{
+  if (!hp || !*hp) return PMG_SUCCESS;
+  pmg_mgmc h = *hp;
+  for (int l = 0; l < h->nlevels; ++l) {
+    mg_level *Lv = &h->lv[l];
+    pmg_grid_destroy(&Lv->g);
+    pmg_mcsor_destroy(&Lv->mc);
+    pmg_dev_free(Lv->b);
+    pmg_dev_free(Lv->x);
+    pmg_dev_free(Lv->r);
+    pmg_dev_free(Lv->P_rowpos);
+    pmg_dev_free(Lv->P_rowptr);
+    pmg_dev_free(Lv->P_col);
+    pmg_dev_free(Lv->P_val);
+    pmg_dev_free(Lv->R_rowpos);
+    pmg_dev_free(Lv->R_rowptr);
+    pmg_dev_free(Lv->R_col);
+    pmg_dev_free(Lv->R_val);
+    hcsr_free(&Lv->A_host);
+    hcsr_free(&Lv->P_host);
+  }
+  pmg_chol_destroy(&h->chol);
+  pmg_dev_free(h->y_lay);
+  pmg_dev_free(h->b_lay);
+  free(h->lv);
+  free(h);
+  *hp = NULL;
+  return PMG_SUCCESS;
+}

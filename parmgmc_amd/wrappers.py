@@ -183,6 +183,99 @@ class GridMCSOR:
             pass
 
 
+class CholSampler:
+    """Exact coarse sampler (reference PCCHOLSAMPLER dense path, src/pc_chols.c:174-291)."""
+
+    def __init__(self, rowptr, colidx, vals):
+        rp, ci, v = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colidx, np.int32), np.ascontiguousarray(vals, np.float64)
+        self.n = len(rp) - 1
+        self._h = C.c_void_p()
+        check(lib.pmg_chol_create_csr(self.n, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, C.byref(self._h)))
+
+    def factor(self) -> np.ndarray:
+        out = np.zeros(self.n * self.n)
+        check(lib.pmg_chol_get_factor(self._h, out.ctypes.data))
+        return out.reshape((self.n, self.n), order="F")
+
+    def sample(self, b, y, seed: int = 0, counter: int = 0, noisy: bool = True):
+        check(lib.pmg_chol_sample(self._h, _ptr(b), _ptr(y), int(noisy), seed, counter, _stream()))
+
+    def destroy(self):
+        if self._h:
+            check(lib.pmg_chol_destroy(C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class MGMC:
+    """Multigrid Monte Carlo on a DMDA hierarchy (reference PCGAMGMC, src/pc_gamgmc.c, with -pc_gamgmc_mg_type mg)."""
+
+    def __init__(self, nx, ny, nz, kappa, levels, keep_host=False):
+        self.nx, self.ny, self.nz, self.n = nx, ny, nz, nx * ny * nz
+        self._h = C.c_void_p()
+        check(lib.pmg_mgmc_create_dmda(nx, ny, nz, kappa, levels, C.byref(self._h)))
+        check(lib.pmg_mgmc_set_keep_host(self._h, int(keep_host)))
+        self.levels = levels
+
+    def set_smoother(self, scaled: bool, omega: float = 1.0, sweep_type: int = capi.SOR_FORWARD_SWEEP, its: int = 1):
+        check(lib.pmg_mgmc_set_smoother(self._h, int(scaled), omega, sweep_type, its))
+
+    def set_coarse(self, kind: str = "cholsampler", its: int = 1):
+        check(lib.pmg_mgmc_set_coarse(self._h, {"cholsampler": 0, "gibbs": 1}[kind], its))
+
+    def setup(self):
+        check(lib.pmg_mgmc_setup(self._h))
+        return self
+
+    def level_dims(self, level: int):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.pmg_mgmc_get_level_dims(self._h, level, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def level_matrix(self, level: int, which: str):
+        w = {"A": 0, "P": 1}[which]
+        nr, nnz = C.c_int32(), C.c_int32()
+        check(lib.pmg_mgmc_get_level_matrix(self._h, level, w, C.byref(nr), C.byref(nnz), None, None, None))
+        rp, ci, v = np.zeros(nr.value + 1, np.int32), np.zeros(nnz.value, np.int32), np.zeros(nnz.value)
+        check(lib.pmg_mgmc_get_level_matrix(self._h, level, w, C.byref(nr), C.byref(nnz), rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+        return rp, ci, v
+
+    def sample(self, b, y, its: int, seed: int, counter0: int = 0, guesszero: bool = False, callback=None) -> int:
+        out = C.c_uint64()
+        if callback is None:
+            cb = None
+        else:
+            import torch
+
+            def _cb(it, ptr, n, _ctx):
+                try:
+                    callback(it, y)  # y is the tensor the library writes the sample into
+                    return 0
+                except Exception:  # pragma: no cover
+                    import traceback
+
+                    traceback.print_exc()
+                    return 77
+
+            cb = capi.SAMPLE_CALLBACK(_cb)
+        check(lib.pmg_mgmc_sample(self._h, _ptr(b), _ptr(y), its, int(guesszero), seed, counter0, C.byref(out), cb, None, _stream()))
+        return out.value
+
+    def destroy(self):
+        if self._h:
+            check(lib.pmg_mgmc_destroy(C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 def vec_set_random_standard_normal(x, seed: int, counter: int = 0):
     """VecSetRandomStandardNormal (reference src/parmgmc.c:70-116) on the counter-based source."""
     check(lib.pmg_vec_set_random_standard_normal(x.numel(), _ptr(x), seed, counter, _stream()))
