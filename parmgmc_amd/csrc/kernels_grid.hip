@@ -237,64 +237,59 @@ __global__ void grid_from_cvec_kernel(pmgk_grid_layout L, const double *__restri
   nat[i + (int64_t)L.nx * (j + (int64_t)L.ny * k)] = cv[(int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + (i >> 1)];
 }
 
-// r = b - A y for both colours (one thread per point of colour c = blockIdx-parity free variant: thread handles
-// the point pair like the sweep).  Row sum in CSR order INCLUDING the diagonal at its place, as MatMult does,
-// then r = b - s  (VecAYPX(w,-1,b), reference src/pc_gamgmc.c:253-254).
-__global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+// r = b - A y on cvecs, one colour per launch, same tiling and XCD-banded order as the sweep.  Row sum in CSR
+// storage order INCLUDING the diagonal at its place (what PETSc MatMult does), then r = b - s
+// (VecAYPX(w,-1,b), reference src/pc_gamgmc.c:253-254).
+__global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int bandw, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
 {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
+  const int k  = blockIdx.z;
+  const int t  = bx * 64 + threadIdx.x;
+  const int j  = by * 4 + ty;
   if (j >= L.ny || 2 * t >= L.sx) return;
   const int kg = k + L.kz0;
   const int p  = (c + j + kg) & 1;
   const int i0 = 4 * t + p, i1 = i0 + 2;
   if (i0 >= L.nx) return;
   const bool    v1   = i1 < L.nx;
-  const int64_t line = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx;
+  const bool    hasS = j > 0, hasN = j < L.ny - 1, hasD = kg > 0, hasU = kg < L.nzg - 1;
+  const int64_t line = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + 2 * t;
   const double *yo   = y + (int64_t)(1 - c) * L.cs + line;
-  const double *ys   = y + (int64_t)c * L.cs + line;
-  const double *bs   = b + (int64_t)c * L.cs + line;
-  double       *rs   = r + (int64_t)c * L.cs + line;
-  const bool    hasD = kg > 0, hasU = kg < L.nzg - 1, hasS = j > 0, hasN = j < L.ny - 1;
-  const d2      zero = {0.0, 0.0};
-  const d2      oc   = ld2(yo + 2 * t);
-  const double  L0   = p ? oc.x : (t > 0 ? yo[2 * t - 1] : 0.0);
-  const double  R0   = p ? oc.y : oc.x;
-  const double  L1   = p ? oc.y : oc.x;
-  const double  R1   = p ? ((2 * t + 2 < L.sx) ? yo[2 * t + 2] : 0.0) : oc.y;
-  const d2      oS   = hasS ? ld2(yo - L.sx + 2 * t) : zero;
-  const d2      oN   = hasN ? ld2(yo + L.sx + 2 * t) : zero;
-  const d2      oD   = hasD ? ld2(yo - L.sp + 2 * t) : zero;
-  const d2      oU   = hasU ? ld2(yo + L.sp + 2 * t) : zero;
-  const d2      bb   = ld2(bs + 2 * t);
-  const d2      yy   = ld2(ys + 2 * t);
+  const int     eo   = p ? (2 * t + 2 < L.sx ? 2 : 1) : (t > 0 ? -1 : 0);
+  const d2      Vc   = ld2(yo);
+  const double  ed   = yo[eo];
+  const d2      oS   = ld2(yo - (hasS ? L.sx : 0));
+  const d2      oN   = ld2(yo + (hasN ? L.sx : 0));
+  const d2      oD   = ld2(yo - (hasD ? L.sp : 0));
+  const d2      oU   = ld2(yo + (hasU ? L.sp : 0));
+  const d2      bb   = ld2(b + (int64_t)c * L.cs + line);
+  const d2      yy   = ld2(y + (int64_t)c * L.cs + line);
+  const double  L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
   const bool    hasW0 = i0 > 0, hasE0 = i0 < L.nx - 1, hasE1 = i1 < L.nx - 1;
-  const int     nyz = (int)hasD + (int)hasU + (int)hasS + (int)hasN;
-  const int     nn0 = nyz + (int)hasW0 + (int)hasE0, nn1 = nyz + 1 + (int)hasE1;
-  const double  a   = -op.h2;
+  const int     nyz = (int)hasS + (int)hasN + (int)hasD + (int)hasU;
+  const double  dA = uniform(op.diag[nyz + 1]), dB = uniform(op.diag[nyz + 2]);
+  const double  dg0 = (hasW0 && hasE0) ? dB : dA, dg1 = hasE1 ? dB : dA;
+  const double  a = -op.h2;
+  const double  aS = hasS ? a : 0.0, aN = hasN ? a : 0.0, aD = hasD ? a : 0.0, aU = hasU ? a : 0.0;
   double        s0 = 0.0, s1 = 0.0;
-  s0 = s0 + a * oD.x;
-  s1 = s1 + a * oD.y;
-  s0 = s0 + a * oS.x;
-  s1 = s1 + a * oS.y;
-  s0 = s0 + a * (hasW0 ? L0 : 0.0);
+  s0 = s0 + aD * oD.x;
+  s1 = s1 + aD * oD.y;
+  s0 = s0 + aS * oS.x;
+  s1 = s1 + aS * oS.y;
+  s0 = s0 + (hasW0 ? a : 0.0) * L0;
   s1 = s1 + a * L1;
-  s0 = s0 + op.diag[nn0] * yy.x;
-  s1 = s1 + op.diag[nn1] * yy.y;
-  s0 = s0 + a * (hasE0 ? R0 : 0.0);
-  s1 = s1 + a * (hasE1 ? R1 : 0.0);
-  s0 = s0 + a * oN.x;
-  s1 = s1 + a * oN.y;
-  s0 = s0 + a * oU.x;
-  s1 = s1 + a * oU.y;
-  const double r0 = bb.x - s0, r1 = bb.y - s1;
-  if (v1) {
-    d2 out = {r0, r1};
-    *reinterpret_cast<d2 *>(rs + 2 * t) = out;
-  } else {
-    rs[2 * t] = r0;
-  }
+  s0 = s0 + dg0 * yy.x;
+  s1 = s1 + dg1 * yy.y;
+  s0 = s0 + (hasE0 ? a : 0.0) * R0;
+  s1 = s1 + (hasE1 ? a : 0.0) * R1;
+  s0 = s0 + aN * oN.x;
+  s1 = s1 + aN * oN.y;
+  s0 = s0 + aU * oU.x;
+  s1 = s1 + aU * oU.y;
+  const d2 out = {bb.x - s0, v1 ? bb.y - s1 : 0.0};
+  *reinterpret_cast<d2 *>(r + (int64_t)c * L.cs + line) = out;
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
@@ -348,9 +343,11 @@ extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_
 extern "C" int pmgk_grid_residual(const pmgk_grid_layout *L, const pmgk_grid_op *op, const double *b, const double *y, double *r, void *stream)
 {
   const int  tpl = L->sx / 2;
+  const int  nbx = (tpl + 63) / 64, nby = (L->ny + 3) / 4;
+  const int  bandw = nby >= 16 ? (nby + 7) / 8 : 0;
   const dim3 block(64, 4, 1);
-  const dim3 grid((tpl + 63) / 64, (L->ny + 3) / 4, L->nz);
-  for (int c = 0; c < 2; ++c) hipLaunchKernelGGL(grid_residual_kernel, grid, block, 0, (hipStream_t)stream, *L, *op, c, b, y, r);
+  const dim3 grid(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, L->nz);
+  for (int c = 0; c < 2; ++c) hipLaunchKernelGGL(grid_residual_kernel, grid, block, 0, (hipStream_t)stream, *L, *op, c, bandw, b, y, r);
   return launch_status();
 }
 

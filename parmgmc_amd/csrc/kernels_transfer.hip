@@ -1,0 +1,80 @@
+// Matrix-free Q1 transfers between a red-black grid level (colour-partitioned cvec) and the next coarser level
+// (any layout, given by a position map) -- gfx950.
+//
+// Replace the two sparse products PCMG issues per level and cycle, MatRestrict (b_c = P^T r) and
+// MatInterpolateAdd (x += P e_c) (PETSc, entered from reference src/pc_gamgmc.c:246,255), for DMDA's Q1
+// interpolation: fine point 2I coincides with coarse I (weight 1), fine 2I+1 lies midway between coarse I and I+1
+// (1/2 each), tensor product over the refined directions.  No matrix is read: 8 B per fine unknown + 8 B per
+// coarse unknown instead of 12 B per stored entry (3.4 entries per fine row for P, 27 per coarse row for P^T).
+// Sums run over the same entries in the same (ascending fine / coarse index) order as the CSR product of the
+// stored transposed / plain interpolation, so results are bit-identical to the assembled operators.
+#include <hip/hip_runtime.h>
+#include "pmg_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int64_t cvec_pos(const pmgk_grid_layout &L, int i, int j, int k)
+{
+  const int c = (i + j + k + L.kz0) & 1;
+  return (int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + (i >> 1);
+}
+
+// b_c[cpos[I]] = sum over the <= 27 fine points 2I+d, d in {-1,0,1}^3 (only refined directions), of w(d) r(2I+d)
+__global__ __launch_bounds__(256) void q1_restrict_kernel(pmgk_grid_layout L, int ncx, int ncy, int ncz, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ r, double *__restrict__ bc)
+{
+  const int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y, K = blockIdx.z;
+  if (I >= ncx) return;
+  const int fi = rx ? 2 * I : I, fj = ry ? 2 * J : J, fk = rz ? 2 * K : K;
+  double    s  = 0.0;
+  for (int dz = rz ? -1 : 0; dz <= (rz ? 1 : 0); ++dz) {
+    const int k = fk + dz;
+    if (k < 0 || k >= L.nz) continue;
+    for (int dy = ry ? -1 : 0; dy <= (ry ? 1 : 0); ++dy) {
+      const int j = fj + dy;
+      if (j < 0 || j >= L.ny) continue;
+      for (int dx = rx ? -1 : 0; dx <= (rx ? 1 : 0); ++dx) {
+        const int i = fi + dx;
+        if (i < 0 || i >= L.nx) continue;
+        const double w = (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0);
+        s              = s + w * r[cvec_pos(L, i, j, k)];
+      }
+    }
+  }
+  bc[cpos[I + ncx * (J + ncy * K)]] = s;
+}
+
+// x[pos(i,j,k)] += sum over the <= 8 coarse points interpolating fine point (i,j,k), ascending coarse index
+__global__ __launch_bounds__(256) void q1_prolong_add_kernel(pmgk_grid_layout L, int ncx, int ncy, int ncz, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ ec, double *__restrict__ x)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+  if (i >= L.nx) return;
+  const int I0 = rx ? i >> 1 : i, J0 = ry ? j >> 1 : j, K0 = rz ? k >> 1 : k;
+  const int mx = (rx && (i & 1)) ? 2 : 1, my = (ry && (j & 1)) ? 2 : 1, mz = (rz && (k & 1)) ? 2 : 1;
+  const double wx = mx == 2 ? 0.5 : 1.0, wy = my == 2 ? 0.5 : 1.0, wz = mz == 2 ? 0.5 : 1.0;
+  double s = 0.0;
+  for (int c = 0; c < mz; ++c)
+    for (int bq = 0; bq < my; ++bq)
+      for (int a = 0; a < mx; ++a) s = s + (wx * wy * wz) * ec[cpos[(I0 + a) + ncx * ((J0 + bq) + ncy * (K0 + c))]];
+  const int64_t p = cvec_pos(L, i, j, k);
+  x[p]            = x[p] + s;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
+
+} // namespace
+
+extern "C" int pmgk_q1_restrict(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *r_cvec, double *bc, void *stream)
+{
+  const int  rx = ncx != L->nx, ry = ncy != L->ny, rz = ncz != L->nz;
+  const dim3 block(64), grid((ncx + 63) / 64, ncy, ncz);
+  hipLaunchKernelGGL(q1_restrict_kernel, grid, block, 0, (hipStream_t)stream, *L, ncx, ncy, ncz, rx, ry, rz, cpos, r_cvec, bc);
+  return launch_status();
+}
+
+extern "C" int pmgk_q1_prolong_add(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *ec, double *x_cvec, void *stream)
+{
+  const int  rx = ncx != L->nx, ry = ncy != L->ny, rz = ncz != L->nz;
+  const dim3 block(64), grid((L->nx + 63) / 64, L->ny, L->nz);
+  hipLaunchKernelGGL(q1_prolong_add_kernel, grid, block, 0, (hipStream_t)stream, *L, ncx, ncy, ncz, rx, ry, rz, cpos, ec, x_cvec);
+  return launch_status();
+}

@@ -58,6 +58,13 @@ pmg_status pmg_grid_create(int32_t nx, int32_t ny, int32_t nzg, int32_t kz0, int
   return PMG_SUCCESS;
 }
 
+pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L)
+{
+  PMG_CHECK(g && L, PMG_ERR_ARG_NULL, "null argument");
+  *L = g->L;
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_grid_destroy(pmg_grid *g)
 {
   if (!g || !*g) return PMG_SUCCESS;

@@ -38,6 +38,9 @@ pmg_status pmg_set_error(pmg_status code, const char *file, int line, const char
 
 static inline int pmg_sweep_type_ok(int t) { return t == PMG_SOR_FORWARD_SWEEP || t == PMG_SOR_BACKWARD_SWEEP || t == PMG_SOR_SYMMETRIC_SWEEP; }
 
+/* kernel-side description of a grid object (internal) */
+pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L);
+
 /* device allocation helpers (zero-filled) */
 pmg_status pmg_dev_alloc(void **p, size_t bytes);
 pmg_status pmg_dev_upload(void **p, const void *host, size_t bytes);

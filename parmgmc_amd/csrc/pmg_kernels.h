@@ -74,6 +74,10 @@ int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, c
 /* y[rowpos[r]] (+)= alpha * sum_k vals[k] x[colidx[k]] over the rows of a CSR block whose output positions are
    given explicitly (transfer operators between level layouts); accumulate != 0 adds to y */
 int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, void *stream);
+/* matrix-free Q1 transfers between a grid level (cvec) and the next coarser level whose layout is given by
+   cpos[natural coarse index] (device array) */
+int pmgk_q1_restrict(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *r_cvec, double *bc, void *stream);
+int pmgk_q1_prolong_add(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *ec, double *x_cvec, void *stream);
 /* triangular matrix-vector products of the coarse exact sampler (row-major n x n, lower or upper part) */
 int pmgk_tri_gemv(int32_t n, int upper, const double *M, const double *x, const double *add, double *out, void *stream);
 int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);

@@ -40,6 +40,7 @@ typedef struct {
   double   *b, *x, *r;
   /* transfers to the next coarser level, in layout numbering on the device */
   int32_t  P_nrows, R_nrows;
+  int32_t *cpos_dev; /* grid level only: layout position of every point of the next coarser level */
   int32_t *P_rowpos, *P_rowptr, *P_col, *R_rowpos, *R_rowptr, *R_col;
   double  *P_val, *R_val;
   /* optional host copies (natural numbering) for inspection */
@@ -403,11 +404,15 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
       for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q;
     }
     if (is_coarsest && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr(Cc->n, Ac.rp, Ac.ci, Ac.v, &h->chol));
-    /* transfers in layout numbering */
-    U->P_nrows = P.nr;
-    U->R_nrows = R.nr;
-    PMG_CALL(upload_transfer(&P, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
-    PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    /* transfers: matrix-free Q1 kernels from the grid level, CSR products in layout numbering below it */
+    if (U->is_grid && !getenv("PMG_MG_CSR_TRANSFERS")) {
+      PMG_CALL(pmg_dev_upload((void **)&U->cpos_dev, pos[l - 1], sizeof(int32_t) * (size_t)Cc->n));
+    } else {
+      U->P_nrows = P.nr;
+      U->R_nrows = R.nr;
+      PMG_CALL(upload_transfer(&P, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
+      PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    }
     hcsr_free(&R);
     if (h->keep_host) U->P_host = P;
     else hcsr_free(&P);
@@ -498,7 +503,13 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, void *st
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
     else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
-    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, Lv->r, Cc->b, 0, stream)); /* MatRestrict */
+    if (Lv->cpos_dev) { /* MatRestrict, matrix-free */
+      pmgk_grid_layout GL;
+      PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
+      PMG_KERNEL(pmgk_q1_restrict(&GL, Cc->nx, Cc->ny, Cc->nz, Lv->cpos_dev, Lv->r, Cc->b, stream));
+    } else {
+      PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, Lv->r, Cc->b, 0, stream)); /* MatRestrict */
+    }
   }
   {
     mg_level *C0 = &h->lv[0];
@@ -511,7 +522,13 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, void *st
   }
   for (int l = 1; l <= top; ++l) {
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
-    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, Cc->x, Lv->x, 1, stream)); /* MatInterpolateAdd */
+    if (Lv->cpos_dev) { /* MatInterpolateAdd, matrix-free */
+      pmgk_grid_layout GL;
+      PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
+      PMG_KERNEL(pmgk_q1_prolong_add(&GL, Cc->nx, Cc->ny, Cc->nz, Lv->cpos_dev, Cc->x, Lv->x, stream));
+    } else {
+      PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, Cc->x, Lv->x, 1, stream)); /* MatInterpolateAdd */
+    }
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
   }
   return PMG_SUCCESS;
@@ -558,6 +575,7 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
     pmg_dev_free(Lv->b);
     pmg_dev_free(Lv->x);
     pmg_dev_free(Lv->r);
+    pmg_dev_free(Lv->cpos_dev);
     pmg_dev_free(Lv->P_rowpos);
     pmg_dev_free(Lv->P_rowptr);
     pmg_dev_free(Lv->P_col);
