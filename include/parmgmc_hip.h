@@ -147,6 +147,10 @@ pmg_status pmg_grid_residual_cvec(pmg_grid g, const double *b_cvec, const double
    w = xi*sqrtdiag + b with noise counter `counter`; the colour-`color` points read the OTHER colour, so the
    ghost planes of colour 1-color must be current. */
 pmg_status pmg_grid_sweep_color_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const double *b_cvec, double *y_cvec, void *stream);
+/* The same restricted to owned planes [kbegin, kbegin+kcount): lets a multi-GPU driver sweep the two boundary
+   planes first, start their halo exchange, and sweep the interior while the exchange is in flight (the overlap
+   PCPARSOR gets from starting `botsct` before the INT1 rows, src/pc_parsor.c:739-745). */
+pmg_status pmg_grid_sweep_color_planes_cvec(pmg_grid g, int color, int32_t kbegin, int32_t kcount, int noisy, int scaled, uint64_t seed, uint64_t counter, const double *b_cvec, double *y_cvec, void *stream);
 /* Where the halo of colour `color` lives inside a cvec (offsets and count in doubles): the owned boundary
    plane on `side` (0 = low k, 1 = high k) that the neighbour needs, and the ghost plane on that side that
    receives the neighbour's plane.  A plane of one colour is one contiguous block, so the exchange that replaces

@@ -97,6 +97,7 @@ _sig = {
     "pmg_grid_sample_cvec": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_grid_residual_cvec": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "pmg_grid_sweep_color_cvec": (_int, [_vp, _int, _int, _int, _u64, _u64, _vp, _vp, _vp]),
+    "pmg_grid_sweep_color_planes_cvec": (_int, [_vp, _int, _i32, _i32, _int, _int, _u64, _u64, _vp, _vp, _vp]),
     "pmg_grid_halo_plane": (_int, [_vp, _int, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "pmg_grid_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_grid_destroy": (_int, [C.POINTER(_vp)]),

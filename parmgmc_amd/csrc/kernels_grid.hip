@@ -45,7 +45,7 @@ __device__ __forceinline__ double uniform(double v)
 // Boundary handling is branch-free: an absent neighbour is read from a clamped (valid, finite) address and
 // enters with coefficient 0 instead of h2, which adds an exact +0.
 template <bool NOISY, bool OMEGA1>
-__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
 {
   // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
   // wave-uniform; readfirstlane tells the compiler, which then keeps the boundary logic on the scalar unit
@@ -296,8 +296,9 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
 
-extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, const double *b, double *y, void *stream)
+extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, const double *b, double *y, void *stream)
 {
+  if (kcount <= 0) return 0;
   const int tpl = L->sx / 2; // threads per line
   static int variant = -1;
   if (variant < 0) {
@@ -306,6 +307,7 @@ extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_
   }
   if (variant == 0) {
     const dim3 block(64, 4, 1);
+    if (kbegin != 0 || kcount != L->nz) return 2; /* the A/B variant sweeps whole slabs only */
     const dim3 grid((tpl + 63) / 64, (L->ny + 3) / 4, L->nz);
     hipStream_t s = (hipStream_t)stream;
     if (op->noisy) {
@@ -326,16 +328,16 @@ extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_
   // XCD-banded dispatch order needs enough line tiles to give every XCD a band
   const int  bandw = (banded_env && nby >= 16) ? (nby + 7) / 8 : 0;
   const dim3 block(64, 4, 1);
-  const dim3 grid(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, L->nz);
+  const dim3 grid(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, kcount);
   hipStream_t   s  = (hipStream_t)stream;
   const double *bo = b + (int64_t)color * L->cs, *yo = y + (int64_t)(1 - color) * L->cs;
   double       *ys = y + (int64_t)color * L->cs;
   if (op->noisy) {
-    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, bo, yo, ys);
-    else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, bo, yo, ys);
+    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, bo, yo, ys);
+    else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, bo, yo, ys);
   } else {
-    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, bo, yo, ys);
-    else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, bo, yo, ys);
+    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, bo, yo, ys);
+    else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, bo, yo, ys);
   }
   return launch_status();
 }

@@ -174,8 +174,8 @@ static pmg_status pmg_grid_one_sweep(pmg_grid g, int dir, int noisy, int scaled,
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, noisy, scaled, seed, sweep);
   const int c0 = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, b, y, stream));
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, b, y, stream));
   return PMG_SUCCESS;
 }
 
@@ -186,7 +186,19 @@ pmg_status pmg_grid_sweep_color_cvec(pmg_grid g, int color, int noisy, int scale
   PMG_CHECK(!noisy || scaled || g->omega == 1.0, PMG_ERR_SUP, "the unscaled (sorgibbs) noise requires omega = 1 (src/pc_sorgibbs.c:94)");
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, noisy != 0, scaled, seed, counter);
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, 0, g->L.nz, b, y, stream));
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_grid_sweep_color_planes_cvec(pmg_grid g, int color, int32_t kbegin, int32_t kcount, int noisy, int scaled, uint64_t seed, uint64_t counter, const double *b, double *y, void *stream)
+{
+  PMG_CHECK(g && b && y, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(color == 0 || color == 1, PMG_ERR_ARG_OUTOFRANGE, "colour %d", color);
+  PMG_CHECK(kbegin >= 0 && kcount >= 0 && kbegin + kcount <= g->L.nz, PMG_ERR_ARG_OUTOFRANGE, "planes [%d,%d) outside the %d owned planes", kbegin, kbegin + kcount, g->L.nz);
+  PMG_CHECK(!noisy || scaled || g->omega == 1.0, PMG_ERR_SUP, "the unscaled (sorgibbs) noise requires omega = 1 (src/pc_sorgibbs.c:94)");
+  pmgk_grid_op op;
+  pmg_grid_fill_op(g, &op, noisy != 0, scaled, seed, counter);
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, kbegin, kcount, b, y, stream));
   return PMG_SUCCESS;
 }
 

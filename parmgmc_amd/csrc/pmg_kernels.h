@@ -41,7 +41,8 @@ typedef struct {
   int32_t  omega_is_one;
 } pmgk_grid_op;
 
-int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, const double *b_cvec, double *y_cvec, void *stream);
+/* sweeps the colour-`color` points of owned planes [kbegin, kbegin+kcount) */
+int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, const double *b_cvec, double *y_cvec, void *stream);
 int pmgk_grid_to_cvec(const pmgk_grid_layout *L, const double *nat, double *cvec, void *stream);
 int pmgk_grid_from_cvec(const pmgk_grid_layout *L, const double *cvec, double *nat, void *stream);
 /* r = b - A y on cvecs (PCMGResidualDefault / src/pc_gamgmc.c:253-254) */

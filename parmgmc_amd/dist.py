@@ -54,16 +54,35 @@ def color_schedule(sweep_type: int):
     return [(0, 1)] if sweep_type == SOR_FORWARD_SWEEP else [(1, 0)]
 
 
-def run_samples(sweep_color, halo: SlabHalo, b, y, its: int, sweep_type: int, counter0: int) -> int:
-    """The distributed sample loop.  sweep_color(color, b, y, counter) sweeps the local points of one colour
-    (HIP kernel in production, an injected CPU kernel in the gloo tests)."""
+def run_samples(sweep_planes, halo: SlabHalo, nz: int, b, y, its: int, sweep_type: int, counter0: int) -> int:
+    """The distributed sample loop with communication/computation overlap.
+
+    sweep_planes(color, kbegin, kcount, b, y, counter) sweeps the local points of one colour on owned planes
+    [kbegin, kbegin+kcount) (HIP kernel in production, an injected CPU kernel in the gloo tests).
+
+    Invariant: the ghost planes of colour c are current once the exchange started after the last sweep of colour
+    c has completed.  Per colour c: wait for the exchange of colour 1-c; sweep the two boundary planes (the only
+    ones that read ghost planes); start the exchange of colour c; sweep the interior planes while it is in
+    flight -- the overlap PCPARSOR gets by starting `botsct` before its INT1 rows (reference
+    src/pc_parsor.c:739-745), here per colour instead of the reference's blocking per-colour VecScatter
+    (src/mc_sor.c:318-319)."""
+    pending = {0: halo.start(y, 0), 1: halo.start(y, 1)}  # the caller's y has no ghost values yet
+    edge = sorted({0, nz - 1})
     ctr = counter0
     for _ in range(its):
         for order in color_schedule(sweep_type):
             for c in order:
-                halo.exchange(y, 1 - c)  # colour c reads colour 1-c across the slab faces
-                sweep_color(c, b, y, ctr)
+                halo.finish(pending[1 - c])  # colour c reads colour 1-c across the slab faces
+                pending[1 - c] = []
+                for k in edge:
+                    sweep_planes(c, k, 1, b, y, ctr)
+                halo.finish(pending[c])  # an older exchange of colour c must not land after the new one starts
+                pending[c] = halo.start(y, c)
+                if nz > 2:
+                    sweep_planes(c, 1, nz - 2, b, y, ctr)
             ctr += 1
+    halo.finish(pending[0])
+    halo.finish(pending[1])
     return ctr
 
 
@@ -86,4 +105,4 @@ class DistGridSampler:
             self.grid.set_sweep_type(self.sweep_type)
             return self.grid.sample_cvec(b, y, its, seed, counter0, self.scaled)
         g = self.grid
-        return run_samples(lambda c, bb, yy, ctr: g.sweep_color_cvec(c, bb, yy, True, self.scaled, seed, ctr), self.halo, b, y, its, self.sweep_type, counter0)
+        return run_samples(lambda c, k0, nk, bb, yy, ctr: g.sweep_color_planes_cvec(c, k0, nk, bb, yy, True, self.scaled, seed, ctr), self.halo, g.nz, b, y, its, self.sweep_type, counter0)

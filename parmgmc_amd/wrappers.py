@@ -163,6 +163,9 @@ class GridMCSOR:
     def sweep_color_cvec(self, color: int, b, y, noisy: bool = False, scaled: bool = True, seed: int = 0, counter: int = 0):
         check(lib.pmg_grid_sweep_color_cvec(self._h, color, int(noisy), int(scaled), seed, counter, _ptr(b), _ptr(y), _stream()))
 
+    def sweep_color_planes_cvec(self, color: int, kbegin: int, kcount: int, b, y, noisy: bool = False, scaled: bool = True, seed: int = 0, counter: int = 0):
+        check(lib.pmg_grid_sweep_color_planes_cvec(self._h, color, kbegin, kcount, int(noisy), int(scaled), seed, counter, _ptr(b), _ptr(y), _stream()))
+
     def halo_plane(self, color: int, side: int):
         """(owned_offset, ghost_offset, count) in doubles inside a cvec."""
         a, b, n = C.c_int64(), C.c_int64(), C.c_int64()

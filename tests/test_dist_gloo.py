@@ -93,16 +93,19 @@ def _worker(rank, world, port, nx, ny, nz, kappa, omega, sweep_type, its, b, y0,
     owned = np.arange(lo * plane, hi * plane, dtype=np.int32)
     L = O.lib()
 
-    def sweep_color(c, _b, yt, ctr):
+    def sweep_planes(c, k0, nk, _b, yt, ctr):
         glob = np.zeros(A.n)
         ext_to_glob(lay.ext_from_cvec(yt.numpy()), glob)
         w = O.prepare_rhs(O.noise_grid(nx, ny, nz, 77, ctr), sd, bglob)
-        rows = np.ascontiguousarray(owned[colors[owned] == c])
+        sel = owned[(lo + k0) * plane - lo * plane:(lo + k0 + nk) * plane - lo * plane]
+        rows = np.ascontiguousarray(sel[colors[sel] == c])
         L.orc_parsor_rows(len(rows), rows, A.rowptr, A.colidx, A.vals, dp, idg, omega, w, glob, None, None, None, None)
-        yt.copy_(torch.from_numpy(lay.cvec_from_ext(glob_to_ext(glob))))
+        # like the HIP kernel, write ONLY the swept points (an exchange into the ghost planes may be in flight)
+        ext_idx = rows - (lo - 1) * plane  # natural index inside the extended slab (planes lo-1 .. hi)
+        yt[torch.from_numpy(lay.pos[ext_idx])] = torch.from_numpy(glob[rows])
 
     halo = SlabHalo(rank, world, lay.planes)
-    ctr = run_samples(sweep_color, halo, None, y, its, sweep_type, 3)
+    ctr = run_samples(sweep_planes, halo, hi - lo, None, y, its, sweep_type, 3)
     glob = np.zeros(A.n)
     ext_to_glob(lay.ext_from_cvec(y.numpy()), glob)
     out_queue.put((rank, lo, hi, glob[lo * plane:hi * plane].copy(), ctr))
@@ -110,11 +113,11 @@ def _worker(rank, world, port, nx, ny, nz, kappa, omega, sweep_type, its, b, y0,
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sweep_type", [O.SOR_FORWARD, O.SOR_SYMMETRIC])
-def test_two_rank_chain_equals_one_domain_chain(sweep_type):
+@pytest.mark.parametrize("sweep_type,world", [(O.SOR_FORWARD, 2), (O.SOR_SYMMETRIC, 2), (O.SOR_BACKWARD, 3)])
+def test_two_rank_chain_equals_one_domain_chain(sweep_type, world):
     import torch.multiprocessing as mp
 
-    nx, ny, nz, kappa, omega, its, world = 6, 5, 7, 2.0, 1.2, 2, 2
+    nx, ny, nz, kappa, omega, its = 6, 5, 7, 2.0, 1.2, 2
     rng = np.random.default_rng(9)
     n = nx * ny * nz
     b, y0 = rng.standard_normal(n), rng.standard_normal(n)

@@ -213,3 +213,26 @@ def test_slab_decomposition_is_bitwise_identical():
         ss.set_omega(1.1)
         got = ss.sample_natural(b, y0, 4, seed=99, counter0=0)
         assert np.array_equal(got, host(yd)), cuts
+
+
+def test_plane_range_sweeps_compose_to_the_full_sweep():
+    """boundary planes first, interior afterwards (the multi-GPU overlap order) == one full colour pass, bitwise."""
+    from parmgmc_amd import GridMCSOR
+
+    nx, ny, nz, kappa = 20, 18, 9, 1.5
+    rng = np.random.default_rng(21)
+    b, y0 = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
+    g = GridMCSOR(nx, ny, nz, kappa)
+    g.set_omega(1.1)
+    bc = g.to_cvec(dev(b))
+    y1, y2 = g.to_cvec(dev(y0)), g.to_cvec(dev(y0))
+    for c in (0, 1):
+        g.sweep_color_cvec(c, bc, y1, True, True, 5, 3)
+        for k0, nk in ((0, 1), (nz - 1, 1), (1, nz - 2)):
+            g.sweep_color_planes_cvec(c, k0, nk, bc, y2, True, True, 5, 3)
+    assert np.array_equal(host(y1), host(y2))
+    from parmgmc_amd import PMGError
+
+    with pytest.raises(PMGError) as e:
+        g.sweep_color_planes_cvec(0, 5, 9, bc, y2)
+    assert e.value.code == 63
