@@ -1,14 +1,164 @@
-// Coarse-grid exact sampler kernels (gfx950): y = W^T (W b + xi) with W = L^-1, L the lower Cholesky factor.
+// Coarse-grid exact sampler kernels (gfx950).
 //
-// Replaces the two BLAS trsv calls of PCApply_CholSampler's dense path (reference src/pc_chols.c:220-260,
-// :284-288: v = L^-1 x; v += xi; y = L^-T v).  A triangular solve is a chain of N dependent steps -- on a GPU
-// that is N kernel-wide synchronisations for a few-thousand-row system -- so the inverse factor is formed once at
-// set-up and each sample is two triangular matrix-vector products, one wavefront per row, reading W (stored
-// twice, row-major lower and row-major upper=W^T) exactly once: 2 * N(N+1)/2 * 8 bytes, HBM/L2 bound.
+// Replaces PCCHOLSAMPLER's dense path (reference src/pc_chols.c): LAPACKpotrf_("L") at set-up (:174-194) and the
+// two BLAS trsv calls per sample, y = L^-T (L^-1 b + xi) (:220-260, :284-288).
+//
+// Set-up (O(N^3) flops, the one place of the sampler where the matrix cores pay): blocked right-looking
+// Cholesky with 32x32 tiles -- diagonal tile factored (and inverted) by one workgroup in LDS, panel = tile *
+// inverse-diagonal^T, trailing update C_ik -= L_ij L_kj^T on v_mfma_f64_16x16x4_f64 (one wavefront per 32x32
+// tile, 4 accumulators x 8 k-steps) -- followed by the blocked inverse W = L^-1, computed anti-diagonal by
+// anti-diagonal with the same MFMA tile product.
+// Per sample: a triangular solve is a chain of N dependent steps, so the sample uses W: two triangular
+// matrix-vector products, one wavefront per row, reading W (stored twice: row-major lower and row-major upper
+// = W^T) exactly once -- HBM/L2 bound, 2 * N(N+1)/2 * 8 bytes.
+//
+// f64 MFMA operand maps (cdna_hip_programming.md section 3): A[row = lane&15][k = lane>>4], B[k = lane>>4][col =
+// lane&15], C/D col = lane&15, row = (lane>>4) + 4*reg.
 #include <hip/hip_runtime.h>
 #include "pmg_kernels.h"
 
 namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int NB = 32;
+
+// acc[2][2] (16x16 sub-tiles of a 32x32 tile) += A(32 x K) * B(K x 32).
+// A(r,k) = a[r + lda*k].  B(k,c) = bt ? b[c + ldb*k] : b[k + ldb*c].
+__device__ __forceinline__ void mfma_tile32(v4d acc[2][2], const double *__restrict__ a, int64_t lda, const double *__restrict__ b, int64_t ldb, bool bt, int K)
+{
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int    k  = k0 + lk;
+    const double a0 = a[lr + lda * k], a1 = a[16 + lr + lda * k];
+    const double b0 = bt ? b[lr + ldb * k] : b[k + ldb * lr];
+    const double b1 = bt ? b[16 + lr + ldb * k] : b[k + ldb * (16 + lr)];
+    acc[0][0]       = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1]       = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0]       = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1]       = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+
+// element (row, col) of the 32x32 tile held by this lane in acc[ti][tj][reg]
+__device__ __forceinline__ int tile_row(int ti, int reg) { return 16 * ti + ((threadIdx.x & 63) >> 4) + 4 * reg; }
+__device__ __forceinline__ int tile_col(int tj) { return 16 * tj + (threadIdx.x & 15); }
+
+// Diagonal tile j: factor in LDS, write L_jj (upper part zeroed) and its inverse Dinv[j] (32x32, column-major).
+// info: 0 or the 1-based order of the first non-positive pivot.
+__global__ __launch_bounds__(1024) void potrf_diag_kernel(double *__restrict__ A, int64_t ld, int j, double *__restrict__ Dinv, int *__restrict__ info)
+{
+  __shared__ double S[NB][NB + 1], W[NB][NB + 1];
+  const int r = threadIdx.x, c = threadIdx.y;
+  double   *T = A + (int64_t)j * NB * (ld + 1);
+  S[r][c]     = T[r + ld * c];
+  __syncthreads();
+  for (int k = 0; k < NB; ++k) {
+    if (r == k && c == k) {
+      const double d = S[k][k];
+      if (!(d > 0.0)) {
+        atomicCAS(info, 0, j * NB + k + 1);
+        S[k][k] = 1.0;
+      } else {
+        S[k][k] = sqrt(d);
+      }
+    }
+    __syncthreads();
+    if (c == k && r > k) S[r][k] = S[r][k] / S[k][k];
+    __syncthreads();
+    if (c > k && r >= c) S[r][c] = S[r][c] - S[r][k] * S[c][k];
+    __syncthreads();
+  }
+  // inverse of the lower-triangular tile by forward substitution, one thread per column
+  if (c == 0) {
+    const int col = r;
+    for (int i = 0; i < NB; ++i) {
+      double s = (i == col) ? 1.0 : 0.0;
+      for (int k = col; k < i; ++k) s -= S[i][k] * W[k][col];
+      W[i][col] = i >= col ? s / S[i][i] : 0.0;
+    }
+  }
+  __syncthreads();
+  T[r + ld * c]                             = r >= c ? S[r][c] : 0.0;
+  Dinv[(int64_t)j * NB * NB + r + NB * c] = W[r][c];
+}
+
+// Panel below diagonal tile j: L_ij = A_ij * Dinv_j^T for every tile row i > j (one workgroup per tile)
+__global__ __launch_bounds__(1024) void potrf_panel_kernel(double *__restrict__ A, int64_t ld, int j, const double *__restrict__ Dinv)
+{
+  __shared__ double At[NB][NB + 1], Dt[NB][NB + 1];
+  const int r = threadIdx.x, c = threadIdx.y;
+  const int i = j + 1 + blockIdx.x;
+  double   *T = A + (int64_t)i * NB + (int64_t)j * NB * ld;
+  At[r][c]    = T[r + ld * c];
+  Dt[r][c]    = Dinv[(int64_t)j * NB * NB + r + NB * c];
+  __syncthreads();
+  double s = 0.0;
+  for (int k = 0; k <= c; ++k) s = fma(At[r][k], Dt[c][k], s); // (Dinv^T)(k,c) = Dinv(c,k), lower triangular
+  T[r + ld * c] = s;
+}
+
+// Trailing update after panel j: C_ik -= L_ij L_kj^T for all tiles i >= k > j; one wavefront per tile.
+__global__ __launch_bounds__(256) void potrf_update_kernel(double *__restrict__ A, int64_t ld, int j, int nt)
+{
+  const int m    = nt - j - 1; // trailing tile rows
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= m * (m + 1) / 2) return;
+  // tile -> (ii >= kk) in the lower triangle, row-major enumeration
+  int ii = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while ((ii + 1) * (ii + 2) / 2 <= tile) ++ii;
+  while (ii * (ii + 1) / 2 > tile) --ii;
+  const int kk = tile - ii * (ii + 1) / 2;
+  const int i = j + 1 + ii, k = j + 1 + kk;
+  v4d       acc[2][2] = {};
+  mfma_tile32(acc, A + (int64_t)i * NB + (int64_t)j * NB * ld, ld, A + (int64_t)k * NB + (int64_t)j * NB * ld, ld, true, NB);
+  double *C = A + (int64_t)i * NB + (int64_t)k * NB * ld;
+  for (int ti = 0; ti < 2; ++ti)
+    for (int tj = 0; tj < 2; ++tj)
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t o = tile_row(ti, reg) + ld * tile_col(tj);
+        C[o]            = C[o] - acc[ti][tj][reg];
+      }
+}
+
+// Inverse, anti-diagonal d >= 1: W_{j+d,j} = -Dinv_{j+d} * sum_{k=j}^{j+d-1} L_{j+d,k} W_{k,j}; one wavefront per j.
+// W holds Dinv on its diagonal tiles (d = 0, written by inv_diag_kernel).
+__global__ __launch_bounds__(64) void inv_step_kernel(const double *__restrict__ L, double *__restrict__ W, int64_t ld, int d, const double *__restrict__ Dinv)
+{
+  __shared__ double T[NB][NB + 1];
+  const int j = blockIdx.x, i = j + d;
+  v4d       acc[2][2] = {};
+  mfma_tile32(acc, L + (int64_t)i * NB + (int64_t)j * NB * ld, ld, W + (int64_t)j * NB + (int64_t)j * NB * ld, ld, false, d * NB);
+  for (int ti = 0; ti < 2; ++ti)
+    for (int tj = 0; tj < 2; ++tj)
+      for (int reg = 0; reg < 4; ++reg) T[tile_row(ti, reg)][tile_col(tj)] = acc[ti][tj][reg];
+  __syncthreads();
+  const double *Di = Dinv + (int64_t)i * NB * NB; // lower triangular, column-major
+  double       *O  = W + (int64_t)i * NB + (int64_t)j * NB * ld;
+  for (int e = threadIdx.x; e < NB * NB; e += 64) {
+    const int r = e & (NB - 1), c = e >> 5;
+    double    s = 0.0;
+    for (int k = 0; k <= r; ++k) s = fma(Di[r + NB * k], T[k][c], s);
+    O[r + ld * c] = -s;
+  }
+}
+
+__global__ void inv_diag_kernel(double *__restrict__ W, int64_t ld, const double *__restrict__ Dinv)
+{
+  const int j = blockIdx.x;
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+    const int r = e & (NB - 1), c = e >> 5;
+    W[(int64_t)j * NB * (ld + 1) + r + ld * c] = Dinv[(int64_t)j * NB * NB + e];
+  }
+}
+
+// out(row-major n x n) = in(column-major, leading dimension ld)^T or plain copy: the two layouts the sampler reads
+__global__ void pack_rowmajor_kernel(int32_t n, const double *__restrict__ in, int64_t ld, int transpose, double *__restrict__ out)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= n) return;
+  // out[r*n + c] = M(r,c) with M = in (transpose = 0) or in^T (transpose = 1)
+  out[(int64_t)r * n + c] = transpose ? in[c + ld * r] : in[r + ld * c];
+}
 
 // out[i] = sum_{k in [lo_i, hi_i)} M[i*n + k] * x[k] (+ add[i]); lower: [0, i+1), upper: [i, n)
 template <bool UPPER>
@@ -29,6 +179,33 @@ __global__ __launch_bounds__(256) void tri_gemv_kernel(int32_t n, const double *
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
+
+// In-place lower Cholesky of the column-major npad x npad matrix A (npad a multiple of 32, padding = identity),
+// then W = L^-1 (column-major, same shape).  Dinv: npad/32 tiles of 32x32 scratch.  info: device int, 0 on entry.
+extern "C" int pmgk_potrf_inverse(int32_t npad, double *A, double *W, double *Dinv, int *info, void *stream)
+{
+  hipStream_t s  = (hipStream_t)stream;
+  const int   nt = npad / NB;
+  for (int j = 0; j < nt; ++j) {
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(NB, NB), 0, s, A, (int64_t)npad, j, Dinv, info);
+    const int m = nt - j - 1;
+    if (m > 0) {
+      hipLaunchKernelGGL(potrf_panel_kernel, dim3(m), dim3(NB, NB), 0, s, A, (int64_t)npad, j, Dinv);
+      const int tiles = m * (m + 1) / 2;
+      hipLaunchKernelGGL(potrf_update_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, A, (int64_t)npad, j, nt);
+    }
+  }
+  hipLaunchKernelGGL(inv_diag_kernel, dim3(nt), dim3(256), 0, s, W, (int64_t)npad, Dinv);
+  for (int d = 1; d < nt; ++d) hipLaunchKernelGGL(inv_step_kernel, dim3(nt - d), dim3(64), 0, s, A, W, (int64_t)npad, d, Dinv);
+  return launch_status();
+}
+
+extern "C" int pmgk_pack_rowmajor(int32_t n, const double *in, int64_t ld, int transpose, double *out, void *stream)
+{
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pack_rowmajor_kernel, dim3((n + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, n, in, ld, transpose, out);
+  return launch_status();
+}
 
 extern "C" int pmgk_tri_gemv(int32_t n, int upper, const double *M, const double *x, const double *add, double *out, void *stream)
 {

@@ -2,41 +2,21 @@
  *
  * Mirrors PCCHOLSAMPLER's dense path (reference src/pc_chols.c): set-up = MatConvert to dense + LAPACK potrf('L')
  * (:174-194), sample = y = L^-T (L^-1 b + xi) (:220-260, :284-288), failure = PETSC_ERR_MAT_CH_ZRPVT with the order
- * of the failing minor (:190).  A triangular solve is a chain of N dependent steps, hopeless on a GPU, so set-up
- * also forms W = L^-1 once (forward substitution on the identity) and a sample is two triangular
- * matrix-vector products on the device (kernels_dense.hip).  Meant for the coarsest grid of the V-cycle
- * (N up to a few thousand); the reference's sparse-direct branch for large N (Pardiso, :195-209) is out of scope.
+ * of the failing minor (:190).  The factorisation runs on the device (blocked, trailing updates on the f64
+ * matrix cores); a triangular solve is a chain of N dependent steps, hopeless on a GPU, so set-up also forms
+ * W = L^-1 once and a sample is two triangular matrix-vector products (kernels_dense.hip).  Meant for the coarsest
+ * grid of the V-cycle (N up to a few tens of thousands); the reference's sparse-direct branch for large N
+ * (Pardiso, :195-209) is out of scope.
  */
 #include "pmg_internal.h"
-#include <math.h>
 
 struct pmg_chol_s {
-  int32_t n;
-  double *W_lo;  /* device, row-major n x n, lower triangle = L^-1         */
-  double *W_up;  /* device, row-major n x n, upper triangle = (L^-1)^T     */
-  double *v, *xi; /* device work vectors                                   */
-  double *L_host; /* host, column-major lower factor (kept for inspection) */
+  int32_t n, npad;
+  double *L_dev;  /* device, column-major npad x npad, lower factor (padding = identity) */
+  double *W_lo;   /* device, row-major n x n, lower triangle = L^-1                     */
+  double *W_up;   /* device, row-major n x n, upper triangle = (L^-1)^T                 */
+  double *v, *xi; /* device work vectors                                                */
 };
-
-/* unblocked lower Cholesky, column-major, in place; returns 0 or the 1-based order of the failing minor */
-static int potrf_lower(int n, double *a)
-{
-  for (int j = 0; j < n; ++j) {
-    double d = a[j + (size_t)n * j];
-    for (int k = 0; k < j; ++k) d -= a[j + (size_t)n * k] * a[j + (size_t)n * k];
-    if (!(d > 0)) return j + 1;
-    d                    = sqrt(d);
-    a[j + (size_t)n * j] = d;
-    /* column update: a[i,j] = (a[i,j] - sum_k a[i,k] a[j,k]) / d, accumulated column by column for stride-1 access */
-    for (int k = 0; k < j; ++k) {
-      const double ajk = a[j + (size_t)n * k];
-      if (ajk != 0.0)
-        for (int i = j + 1; i < n; ++i) a[i + (size_t)n * j] -= a[i + (size_t)n * k] * ajk;
-    }
-    for (int i = j + 1; i < n; ++i) a[i + (size_t)n * j] /= d;
-  }
-  return 0;
-}
 
 pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, pmg_chol *out)
 {
@@ -44,49 +24,40 @@ pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr, const int32_t *
   *out = NULL;
   PMG_CHECK(n >= 1, PMG_ERR_ARG_OUTOFRANGE, "n = %d", n);
   PMG_CHECK(rowptr && colidx && vals, PMG_ERR_ARG_NULL, "null CSR array");
-  PMG_CHECK((double)n * n * 8 * 4 < 64e9, PMG_ERR_SUP, "dense coarse sampler limited to a few tens of thousands of rows (n = %d); coarsen further", n);
-  const size_t nn = (size_t)n * n;
+  const int32_t npad = (n + 31) / 32 * 32;
+  PMG_CHECK((double)npad * npad * 8 * 4 < 96e9, PMG_ERR_SUP, "dense coarse sampler limited to a few tens of thousands of rows (n = %d); coarsen further", n);
+  const size_t nn = (size_t)npad * npad;
   double      *A  = (double *)calloc(nn, sizeof(double));
-  double      *W  = (double *)calloc(nn, sizeof(double));
-  double      *T  = (double *)calloc(nn, sizeof(double));
-  if (!A || !W || !T) {
-    free(A); free(W); free(T);
-    PMG_FAIL(PMG_ERR_MEM, "out of host memory for the %d x %d coarse factor", n, n);
-  }
+  PMG_CHECK(A, PMG_ERR_MEM, "out of host memory for the %d x %d coarse matrix", n, n);
   for (int32_t r = 0; r < n; ++r)
-    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) A[r + (size_t)n * colidx[k]] = vals[k]; /* MatConvert(S, MATSEQDENSE), :184 */
-  const int info = potrf_lower(n, A);
-  if (info) {
-    free(A); free(W); free(T);
-    PMG_FAIL(PMG_ERR_MAT_CH_ZRPVT, "Dense Cholesky failed: leading minor of order %d is not positive definite", info); /* :190 */
-  }
-  /* W = L^-1 by forward substitution on the identity, column by column (W is lower triangular) */
-  for (int c = 0; c < n; ++c) {
-    double *w = W + (size_t)n * c; /* column c of W, column-major */
-    w[c]      = 1.0 / A[c + (size_t)n * c];
-    for (int i = c + 1; i < n; ++i) {
-      double s = 0.0;
-      for (int k = c; k < i; ++k) s -= A[i + (size_t)n * k] * w[k];
-      w[i] = s / A[i + (size_t)n * i];
-    }
-  }
+    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) A[r + (size_t)npad * colidx[k]] = vals[k]; /* MatConvert(S, MATSEQDENSE), :184 */
+  for (int32_t r = n; r < npad; ++r) A[r + (size_t)npad * r] = 1.0;
   pmg_chol ch = (pmg_chol)calloc(1, sizeof *ch);
   if (!ch) {
-    free(A); free(W); free(T);
+    free(A);
     PMG_FAIL(PMG_ERR_MEM, "out of host memory");
   }
-  ch->n      = n;
-  ch->L_host = A;
-  /* row-major lower copy: W_lo[i*n + k] = W(i,k) = W_colmajor[i + n*k] */
-  for (int i = 0; i < n; ++i)
-    for (int k = 0; k <= i; ++k) T[(size_t)i * n + k] = W[i + (size_t)n * k];
-  pmg_status st = pmg_dev_upload((void **)&ch->W_lo, T, nn * sizeof(double));
-  /* row-major upper copy of W^T: W_up[i*n + k] = W(k,i), k >= i; column-major W is exactly that array */
-  if (!st) st = pmg_dev_upload((void **)&ch->W_up, W, nn * sizeof(double));
+  ch->n    = n;
+  ch->npad = npad;
+  double    *W = NULL, *Dinv = NULL;
+  int       *info_dev = NULL, info = 0;
+  pmg_status st = pmg_dev_upload((void **)&ch->L_dev, A, nn * sizeof(double));
+  free(A);
+  if (!st) st = pmg_dev_alloc((void **)&W, nn * sizeof(double));
+  if (!st) st = pmg_dev_alloc((void **)&Dinv, sizeof(double) * 32 * 32 * (size_t)(npad / 32));
+  if (!st) st = pmg_dev_alloc((void **)&info_dev, sizeof(int));
+  if (!st) st = pmg_dev_alloc((void **)&ch->W_lo, sizeof(double) * (size_t)n * n);
+  if (!st) st = pmg_dev_alloc((void **)&ch->W_up, sizeof(double) * (size_t)n * n);
   if (!st) st = pmg_dev_alloc((void **)&ch->v, sizeof(double) * (size_t)n);
   if (!st) st = pmg_dev_alloc((void **)&ch->xi, sizeof(double) * (size_t)n);
-  free(W);
-  free(T);
+  if (!st && pmgk_potrf_inverse(npad, ch->L_dev, W, Dinv, info_dev, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "Cholesky kernels failed to launch"); /* LAPACKpotrf_("L"), :188 */
+  if (!st && pmgk_pack_rowmajor(n, W, npad, 0, ch->W_lo, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "pack kernel failed to launch");
+  if (!st && pmgk_pack_rowmajor(n, W, npad, 1, ch->W_up, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "pack kernel failed to launch");
+  if (!st && hipMemcpy(&info, info_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device Cholesky failed");
+  pmg_dev_free(W);
+  pmg_dev_free(Dinv);
+  pmg_dev_free(info_dev);
+  if (!st && info) st = pmg_set_error(PMG_ERR_MAT_CH_ZRPVT, __FILE__, __LINE__, "Dense Cholesky failed: leading minor of order %d is not positive definite", info); /* :190 */
   if (st) {
     pmg_chol_destroy(&ch);
     return st;
@@ -98,8 +69,15 @@ pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr, const int32_t *
 pmg_status pmg_chol_get_factor(pmg_chol ch, double *L_colmajor_host)
 {
   PMG_CHECK(ch && L_colmajor_host, PMG_ERR_ARG_NULL, "null argument");
+  double *tmp = (double *)malloc(sizeof(double) * (size_t)ch->npad * ch->npad);
+  PMG_CHECK(tmp, PMG_ERR_MEM, "out of host memory");
+  if (hipMemcpy(tmp, ch->L_dev, sizeof(double) * (size_t)ch->npad * ch->npad, hipMemcpyDeviceToHost) != hipSuccess) {
+    free(tmp);
+    PMG_FAIL(PMG_ERR_GPU, "download of the factor failed");
+  }
   for (int j = 0; j < ch->n; ++j)
-    for (int i = 0; i < ch->n; ++i) L_colmajor_host[i + (size_t)ch->n * j] = i >= j ? ch->L_host[i + (size_t)ch->n * j] : 0.0;
+    for (int i = 0; i < ch->n; ++i) L_colmajor_host[i + (size_t)ch->n * j] = i >= j ? tmp[i + (size_t)ch->npad * j] : 0.0;
+  free(tmp);
   return PMG_SUCCESS;
 }
 
@@ -120,7 +98,7 @@ pmg_status pmg_chol_destroy(pmg_chol *ch)
   pmg_dev_free((*ch)->W_up);
   pmg_dev_free((*ch)->v);
   pmg_dev_free((*ch)->xi);
-  free((*ch)->L_host);
+  pmg_dev_free((*ch)->L_dev);
   free(*ch);
   *ch = NULL;
   return PMG_SUCCESS;

@@ -79,6 +79,9 @@ int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowp
    cpos[natural coarse index] (device array) */
 int pmgk_q1_restrict(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *r_cvec, double *bc, void *stream);
 int pmgk_q1_prolong_add(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *ec, double *x_cvec, void *stream);
+/* dense lower Cholesky in place + W = L^-1 on the device (npad multiple of 32; MFMA f64 trailing updates) */
+int pmgk_potrf_inverse(int32_t npad, double *A_colmajor, double *W_colmajor, double *Dinv_scratch, int *info_dev, void *stream);
+int pmgk_pack_rowmajor(int32_t n, const double *in_colmajor, int64_t ld, int transpose, double *out_rowmajor, void *stream);
 /* triangular matrix-vector products of the coarse exact sampler (row-major n x n, lower or upper part) */
 int pmgk_tri_gemv(int32_t n, int upper, const double *M, const double *x, const double *add, double *out, void *stream);
 int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);

@@ -188,3 +188,26 @@ def test_ex1_geometric_mgmc_mean_on_device():
     mg.sample(b, y, 20000, seed=0xCAFE, counter0=ctr, callback=cb)
     ex = np.linalg.solve(O.shifted_laplace(9, 9, 1, 10.0).dense(), np.ones(81))
     assert np.linalg.norm(host(mean) - ex) / np.linalg.norm(ex) < 0.14
+
+
+@pytest.mark.parametrize("n3", [4, 9, 13])
+def test_device_cholesky_mfma_matches_oracle(n3):
+    """The device potrf (f64 MFMA trailing updates) + blocked inverse against the oracle's scalar potrf, sizes that
+    are / are not multiples of the 32-wide tile and need several panel steps (13^3 = 2197 rows = 69 tiles)."""
+    from parmgmc_amd import CholSampler
+
+    A = O.shifted_laplace(n3, n3, n3, 1.0)
+    ch = CholSampler(A.rowptr, A.colidx, A.vals)
+    L = np.linalg.cholesky(A.dense())
+    got = ch.factor()
+    assert np.abs(got - L).max() / np.abs(L).max() < 1e-12
+    rng = np.random.default_rng(n3)
+    b = rng.standard_normal(A.n)
+    y = dev(np.zeros(A.n))
+    ch.sample(dev(b), y, noisy=False)
+    x = np.linalg.solve(A.dense(), b)
+    assert np.abs(host(y) - x).max() / np.abs(x).max() < 1e-11
+    ch.sample(dev(b), y, seed=3, counter=4)
+    xi = O.noise_rows(A.n, 3, 4)
+    want = np.linalg.solve(L.T, np.linalg.solve(L, b) + xi)
+    assert np.abs(host(y) - want).max() / np.abs(want).max() < 1e-11
