@@ -215,6 +215,76 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *mg);
 /* ------------------------------------------------------------------------------------------------------ */
 pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t seed, uint64_t counter, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------ */
+/* The registration boundary without PETSc: PCRegister / PCSetType / pc->ops / PCSetSampleCallback /        */
+/* PCSHELL / KSPRICHARDSON on raw device arrays (reference src/parmgmc.c:44-54,118-151; examples/ex1.c,     */
+/* ex3.c, ex8.c).  With PETSc present the same constructors are bound through the adapter of INTEGRATION.md. */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef struct pmg_pc_s  *pmg_pc;
+typedef struct pmg_mat_s *pmg_mat;
+
+/* ParMGMCInitialize / ParMGMCFinalize (src/parmgmc.c:118-137): registers "sorgibbs", "mcgibbs", "gamgmc",
+   "cholsampler", "parsor" (include/parmgmc/parmgmc.h:26-31) and "shell". */
+pmg_status pmg_initialize(void);
+pmg_status pmg_finalize(void);
+/* PCRegister(name, ctor) (src/parmgmc.c:44-54); the constructor fills the ops of a fresh PC. */
+pmg_status pmg_pc_register(const char *name, pmg_status (*ctor)(pmg_pc));
+/* seed of the library-wide random source (PetscRandomSetSeed on ParMGMCGetPetscRandom, src/parmgmc.c:56-68);
+   every PC draws from its own counter-based stream derived from it */
+pmg_status pmg_set_seed(uint64_t seed);
+/* PetscOptionsSetValue / clear: option names as in the reference, e.g. "-pc_mcgibbs_omega" (src/pc_mcgibbs.c:197),
+   "-pc_sorgibbs_forward" (src/pc_sorgibbs.c:271), "-gamgmc_mg_levels_ksp_max_it" (src/pc_gamgmc.c:324) */
+pmg_status pmg_options_set_value(const char *name, const char *value);
+pmg_status pmg_options_clear(void);
+
+/* operators: a MATSEQAIJ as borrowed host CSR, or the DMDA operator of MatAssembleShiftedLaplaceFD */
+pmg_status pmg_mat_create_csr(int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host, pmg_mat *mat);
+pmg_status pmg_mat_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa, pmg_mat *mat);
+pmg_status pmg_mat_get_size(pmg_mat mat, int32_t *n);
+pmg_status pmg_mat_destroy(pmg_mat *mat);
+
+/* PCCreate / PCSetType / PCSetOptionsPrefix / PCSetOperators / PCSetFromOptions / PCSetUp / PCView / PCReset /
+   PCDestroy.  The operator is borrowed, not referenced (src/pc_sorgibbs.c:35-38). */
+pmg_status pmg_pc_create(pmg_pc *pc);
+pmg_status pmg_pc_set_type(pmg_pc pc, const char *type);
+pmg_status pmg_pc_get_type(pmg_pc pc, char *buf, int32_t len);
+pmg_status pmg_pc_set_options_prefix(pmg_pc pc, const char *prefix);
+pmg_status pmg_pc_set_operators(pmg_pc pc, pmg_mat mat);
+pmg_status pmg_pc_set_from_options(pmg_pc pc);
+pmg_status pmg_pc_setup(pmg_pc pc);
+pmg_status pmg_pc_view(pmg_pc pc, char *buf, int32_t len);
+pmg_status pmg_pc_reset(pmg_pc pc);
+pmg_status pmg_pc_destroy(pmg_pc *pc);
+/* PCApply: sorgibbs (zero y + one sample, src/pc_sorgibbs.c:105-113), cholsampler, parsor, shell; mcgibbs and
+   gamgmc only provide applyrichardson (src/pc_mcgibbs.c:318-325) -> PMG_ERR_SUP, as PETSc reports. */
+pmg_status pmg_pc_apply(pmg_pc pc, const double *b_dev, double *y_dev, void *stream);
+/* PCApplyRichardson: `its` samples, callback after each; tolerances / work vector of the PETSc signature are
+   ignored by every sampler (src/pc_sorgibbs.c:117-120) and therefore absent; *outits = its, *reason = 4
+   (PCRICHARDSON_CONVERGED_ITS). */
+pmg_status pmg_pc_apply_richardson(pmg_pc pc, const double *b_dev, double *y_dev, int32_t its, int guesszero, int32_t *outits, int32_t *reason, void *stream);
+/* KSPSolve with -ksp_type richardson and KSP_NORM_NONE (examples/ex1.c:97-129): all max_it iterations in one
+   applyrichardson call; guess_nonzero = KSPSetInitialGuessNonzero. */
+pmg_status pmg_ksp_richardson_solve(pmg_pc pc, const double *b_dev, double *y_dev, int32_t max_it, int guess_nonzero, void *stream);
+/* PCSetSampleCallback(pc, cb, ctx, deleter) (src/parmgmc.c:146-151): replaces and deletes a previous context;
+   the deleter also runs in reset/destroy (src/pc_sorgibbs.c:153-156,173-176). */
+pmg_status pmg_pc_set_sample_callback(pmg_pc pc, pmg_sample_callback cb, void *ctx, int (*deleter)(void *ctx));
+/* Checkpoint / resume (the reference has none: chain state is the caller's Vec plus the RNG state; with the
+   counter-based source that state is two integers): the effective Philox seed of this PC's stream and the
+   counter of its next draw.  Restoring y and the counter continues a chain bit for bit. */
+pmg_status pmg_pc_get_noise_state(pmg_pc pc, uint64_t *seed, uint64_t *counter);
+pmg_status pmg_pc_set_noise_counter(pmg_pc pc, uint64_t counter);
+/* programmatic setters of the headers under include/parmgmc/pc/ */
+pmg_status pmg_pc_mcgibbs_set_omega(pmg_pc pc, double omega);
+pmg_status pmg_pc_mcgibbs_set_sweep_type(pmg_pc pc, int type);
+pmg_status pmg_pc_parsor_set_omega(pmg_pc pc, double omega);
+pmg_status pmg_pc_parsor_set_iterations(pmg_pc pc, int32_t its);
+pmg_status pmg_pc_parsor_apply_sor(pmg_pc pc, const double *b_dev, int32_t its, int zero_initial_guess, double *x_dev, void *stream);
+pmg_status pmg_pc_gamgmc_set_levels(pmg_pc pc, int32_t levels);
+/* PCSHELL: PCShellSetApply / PCShellSetContext / PCShellGetContext (examples/ex3.c:59-67,128-131) */
+pmg_status pmg_pc_shell_set_apply(pmg_pc pc, pmg_status (*apply)(pmg_pc pc, const double *x_dev, double *y_dev, void *stream));
+pmg_status pmg_pc_shell_set_context(pmg_pc pc, void *ctx);
+pmg_status pmg_pc_shell_get_context(pmg_pc pc, void **ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ def declared_symbols() -> list[str]:
     """Every function name the public header declares (used by the export test)."""
     text = header_path().read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pmg_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(pmg_[a-z0-9_]+)\s*\((?!\*)", text)))
 
 
 def _share_torch_hip_runtime() -> None:
@@ -115,6 +115,41 @@ _sig = {
     "pmg_mgmc_get_level_matrix": (_int, [_vp, _i32, _int, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _vp]),
     "pmg_mgmc_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp, _vp, _vp]),
     "pmg_mgmc_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_initialize": (_int, []),
+    "pmg_finalize": (_int, []),
+    "pmg_pc_register": (_int, [C.c_char_p, _vp]),
+    "pmg_set_seed": (_int, [_u64]),
+    "pmg_options_set_value": (_int, [C.c_char_p, C.c_char_p]),
+    "pmg_options_clear": (_int, []),
+    "pmg_mat_create_csr": (_int, [_i32, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pmg_mat_create_dmda": (_int, [_i32, _i32, _i32, _dbl, C.POINTER(_vp)]),
+    "pmg_mat_get_size": (_int, [_vp, C.POINTER(_i32)]),
+    "pmg_mat_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_pc_create": (_int, [C.POINTER(_vp)]),
+    "pmg_pc_set_type": (_int, [_vp, C.c_char_p]),
+    "pmg_pc_get_type": (_int, [_vp, C.c_char_p, _i32]),
+    "pmg_pc_set_options_prefix": (_int, [_vp, C.c_char_p]),
+    "pmg_pc_set_operators": (_int, [_vp, _vp]),
+    "pmg_pc_set_from_options": (_int, [_vp]),
+    "pmg_pc_setup": (_int, [_vp]),
+    "pmg_pc_view": (_int, [_vp, C.c_char_p, _i32]),
+    "pmg_pc_reset": (_int, [_vp]),
+    "pmg_pc_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_pc_apply": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_pc_apply_richardson": (_int, [_vp, _vp, _vp, _i32, _int, C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "pmg_ksp_richardson_solve": (_int, [_vp, _vp, _vp, _i32, _int, _vp]),
+    "pmg_pc_set_sample_callback": (_int, [_vp, _vp, _vp, _vp]),
+    "pmg_pc_get_noise_state": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "pmg_pc_set_noise_counter": (_int, [_vp, _u64]),
+    "pmg_pc_mcgibbs_set_omega": (_int, [_vp, _dbl]),
+    "pmg_pc_mcgibbs_set_sweep_type": (_int, [_vp, _int]),
+    "pmg_pc_parsor_set_omega": (_int, [_vp, _dbl]),
+    "pmg_pc_parsor_set_iterations": (_int, [_vp, _i32]),
+    "pmg_pc_parsor_apply_sor": (_int, [_vp, _vp, _i32, _int, _vp, _vp]),
+    "pmg_pc_gamgmc_set_levels": (_int, [_vp, _i32]),
+    "pmg_pc_shell_set_apply": (_int, [_vp, _vp]),
+    "pmg_pc_shell_set_context": (_int, [_vp, _vp]),
+    "pmg_pc_shell_get_context": (_int, [_vp, C.POINTER(_vp)]),
     "pmg_vec_set_random_standard_normal": (_int, [_i64, _vp, _u64, _u64, _vp]),
 }
 for _name, (_res, _args) in _sig.items():
@@ -122,6 +157,9 @@ for _name, (_res, _args) in _sig.items():
     _f.restype, _f.argtypes = _res, _args
 
 
+DELETER = C.CFUNCTYPE(C.c_int, C.c_void_p)
+SHELL_APPLY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+PC_CTOR = C.CFUNCTYPE(C.c_int, C.c_void_p)
 SAMPLE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p)
 
 

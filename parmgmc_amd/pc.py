@@ -1,0 +1,142 @@
+"""Python mirror of the PC layer (include/parmgmc_hip.h, "registration boundary" section): what a user of the
+reference writes against PETSc's KSP/PC API (reference examples/ex1.c, ex3.c, ex8.c) written against the C-ABI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, lib
+from .wrappers import _ptr, _stream
+
+
+def initialize():
+    """ParMGMCInitialize (reference src/parmgmc.c:118-127)."""
+    check(lib.pmg_initialize())
+
+
+def finalize():
+    check(lib.pmg_finalize())
+
+
+def options_set_value(name: str, value: str = ""):
+    check(lib.pmg_options_set_value(name.encode(), str(value).encode()))
+
+
+def options_clear():
+    check(lib.pmg_options_clear())
+
+
+def set_seed(seed: int):
+    check(lib.pmg_set_seed(seed))
+
+
+class Mat:
+    def __init__(self, handle, keep=None):
+        self._h, self._keep = handle, keep
+
+    @staticmethod
+    def csr(rowptr, colidx, vals) -> "Mat":
+        rp, ci, v = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colidx, np.int32), np.ascontiguousarray(vals, np.float64)
+        h = C.c_void_p()
+        check(lib.pmg_mat_create_csr(len(rp) - 1, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, C.byref(h)))
+        return Mat(h, (rp, ci, v))
+
+    @staticmethod
+    def dmda(nx, ny, nz, kappa) -> "Mat":
+        h = C.c_void_p()
+        check(lib.pmg_mat_create_dmda(nx, ny, nz, kappa, C.byref(h)))
+        return Mat(h)
+
+    @property
+    def size(self) -> int:
+        n = C.c_int32()
+        check(lib.pmg_mat_get_size(self._h, C.byref(n)))
+        return n.value
+
+
+class PC:
+    def __init__(self, pc_type: str | None = None, prefix: str = ""):
+        self._h = C.c_void_p()
+        check(lib.pmg_pc_create(C.byref(self._h)))
+        self._cb_keep = []
+        if prefix:
+            check(lib.pmg_pc_set_options_prefix(self._h, prefix.encode()))
+        if pc_type:
+            self.set_type(pc_type)
+
+    def set_type(self, t: str):
+        check(lib.pmg_pc_set_type(self._h, t.encode()))
+
+    def get_type(self) -> str:
+        buf = C.create_string_buffer(64)
+        check(lib.pmg_pc_get_type(self._h, buf, 64))
+        return buf.value.decode()
+
+    def set_operators(self, mat: Mat):
+        self._mat = mat
+        check(lib.pmg_pc_set_operators(self._h, mat._h))
+
+    def set_from_options(self):
+        check(lib.pmg_pc_set_from_options(self._h))
+
+    def setup(self):
+        check(lib.pmg_pc_setup(self._h))
+
+    def view(self) -> str:
+        buf = C.create_string_buffer(512)
+        check(lib.pmg_pc_view(self._h, buf, 512))
+        return buf.value.decode()
+
+    def apply(self, b, y):
+        check(lib.pmg_pc_apply(self._h, _ptr(b), _ptr(y), _stream()))
+
+    def apply_richardson(self, b, y, its: int, guesszero: bool = False):
+        outits, reason = C.c_int32(), C.c_int32()
+        check(lib.pmg_pc_apply_richardson(self._h, _ptr(b), _ptr(y), its, int(guesszero), C.byref(outits), C.byref(reason), _stream()))
+        return outits.value, reason.value
+
+    def ksp_solve(self, b, y, max_it: int, guess_nonzero: bool = True):
+        """KSPSolve, -ksp_type richardson (reference examples/ex1.c:123-129)."""
+        check(lib.pmg_ksp_richardson_solve(self._h, _ptr(b), _ptr(y), max_it, int(guess_nonzero), _stream()))
+
+    def set_sample_callback(self, fn, y_tensor, deleter=None):
+        """fn(it, y_tensor) after every sample; y_tensor is the solution tensor passed to the solve."""
+
+        def _cb(it, _ptr_, _n, _ctx):
+            try:
+                fn(it, y_tensor)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+
+                traceback.print_exc()
+                return 77
+
+        cb = capi.SAMPLE_CALLBACK(_cb)
+        dl = capi.DELETER(lambda _c: (deleter() if deleter else None) or 0)
+        self._cb_keep.append((cb, dl))
+        check(lib.pmg_pc_set_sample_callback(self._h, cb, None, dl if deleter else None))
+
+    def noise_state(self):
+        """(effective Philox seed of this PC's stream, counter of its next draw)."""
+        s, c = C.c_uint64(), C.c_uint64()
+        check(lib.pmg_pc_get_noise_state(self._h, C.byref(s), C.byref(c)))
+        return s.value, c.value
+
+    def set_noise_counter(self, counter: int):
+        check(lib.pmg_pc_set_noise_counter(self._h, counter))
+
+    def reset(self):
+        check(lib.pmg_pc_reset(self._h))
+
+    def destroy(self):
+        if self._h:
+            check(lib.pmg_pc_destroy(C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
