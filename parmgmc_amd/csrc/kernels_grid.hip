@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
   // is the XCD], or (nbx, nby, nz) in plain order
   const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
-  const int k  = blockIdx.z;
+  const int k  = kbegin + (int)blockIdx.z;
   const int t = bx * 64 + threadIdx.x;
   const int j = by * 4 + ty;
   if (j >= L.ny || 2 * t >= L.sx) return;
