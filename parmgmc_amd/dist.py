@@ -26,19 +26,36 @@ class SlabHalo:
         self.rank, self.world, self.planes, self.group = rank, world, planes, group
 
     def start(self, y, color: int):
+        import torch
         import torch.distributed as dist
 
-        ops = []
+        # RCCL ("nccl") moves device memory directly over xGMI.  The gloo backend (CPU tests, and the two-ranks-
+        # on-one-GPU test where RCCL cannot be used) needs host buffers: stage device planes through the host.
+        staged = y.is_cuda and dist.get_backend(self.group) == "gloo"
+        ops, post = [], []
         for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
             if peer < 0 or peer >= self.world:
                 continue
             own, ghost, n = self.planes[color][side]
-            ops.append(dist.P2POp(dist.isend, y[own:own + n], peer, self.group))
-            ops.append(dist.P2POp(dist.irecv, y[ghost:ghost + n], peer, self.group))
-        return dist.batch_isend_irecv(ops) if ops else []
+            if staged:
+                snd, rcv = y[own:own + n].cpu(), torch.empty(n, dtype=y.dtype)
+                post.append((ghost, n, rcv))
+            else:
+                snd, rcv = y[own:own + n], y[ghost:ghost + n]
+            ops.append(dist.P2POp(dist.isend, snd, peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, rcv, peer, self.group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        return (reqs, post, y) if staged else reqs
 
     @staticmethod
     def finish(reqs):
+        if isinstance(reqs, tuple):
+            works, post, y = reqs
+            for r in works:
+                r.wait()
+            for ghost, n, rcv in post:
+                y[ghost:ghost + n].copy_(rcv)
+            return
         for r in reqs:
             r.wait()
 

@@ -1,0 +1,74 @@
+"""Two ranks sharing the ONE GPU of the test box: the production multi-device driver (`DistGridSampler`:
+slab ownership, boundary-first overlap schedule, HIP plane-range kernels, halo exchange through
+torch.distributed) against the single-device chain.  RCCL cannot run two ranks on one device, so the exchange
+goes through the `gloo` backend (staged through host memory by SlabHalo when the tensors are on the GPU); the
+kernels and the schedule are exactly the ones `bench.py --gpus N` runs with backend nccl."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nx, ny, nz, kappa, omega, sweep_type, its, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from parmgmc_amd.dist import DistGridSampler
+
+    smp = DistGridSampler(nx, ny, nz, kappa, rank, world, omega=omega, sweep_type=sweep_type)
+    g = smp.grid
+    rng = np.random.default_rng(5)
+    b_all, y_all = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
+    lo, hi = g.kz0 * nx * ny, (g.kz0 + g.nz) * nx * ny
+    b = g.to_cvec(torch.as_tensor(b_all[lo:hi], device="cuda"))
+    y = g.to_cvec(torch.as_tensor(y_all[lo:hi], device="cuda"))
+    ctr = smp.sample_cvec(b, y, its, seed=42, counter0=1)
+    torch.cuda.synchronize()
+    q.put((rank, g.from_cvec(y).cpu().numpy(), ctr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sweep_type,world", [(1, 2), (3, 3)])
+def test_ranks_on_one_gpu_reproduce_the_single_device_chain(sweep_type, world):
+    import torch
+    import torch.multiprocessing as mp
+
+    from parmgmc_amd import GridMCSOR
+
+    nx, ny, nz, kappa, omega, its = 40, 18, 11, 1.5, 1.1, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, ny, nz, kappa, omega, sweep_type, its, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = np.concatenate([x[1] for x in parts])
+    rng = np.random.default_rng(5)
+    b_all, y_all = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
+    one = GridMCSOR(nx, ny, nz, kappa)
+    one.set_omega(omega)
+    one.set_sweep_type(sweep_type)
+    yd = torch.as_tensor(y_all, device="cuda")
+    ctr = one.sample(torch.as_tensor(b_all, device="cuda"), yd, its, seed=42, counter0=1)
+    assert np.array_equal(got, yd.cpu().numpy())  # bit-identical chain for any number of ranks
+    assert all(x[2] == ctr for x in parts)
