@@ -189,6 +189,14 @@ typedef int (*pmg_sample_callback)(int32_t it, const double *y_nat_dev, int32_t 
    odd).  Defaults = the options PCGAMGMC injects (src/pc_gamgmc.c:299-350): level sampler sorgibbs, 1 sweep
    before and after, coarse cholsampler, Galerkin coarse operators. */
 pmg_status pmg_mgmc_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa, int32_t levels, pmg_mgmc *mg);
+/* The same sampler on a hierarchy handed over level by level (level 0 = coarsest): the level operators and
+   interpolations PCGAMGMC finds inside PETSc's PCMG / PCGAMG after PCSetUp (PCMGGetSmoother + PCGetOperators,
+   PCMGGetInterpolation: src/pc_gamgmc.c:165-176), e.g. a GAMG hierarchy of an unstructured P1 matrix
+   (-pc_gamgmc_mg_type gamg, the reference's default).  Host CSR arrays are borrowed until pmg_mgmc_setup. */
+pmg_status pmg_mgmc_create_hierarchy(int32_t levels, pmg_mgmc *mg);
+pmg_status pmg_mgmc_set_level_operator(pmg_mgmc mg, int32_t level, int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host);
+/* interpolation from level-1 (ncols unknowns) to `level` (nrows unknowns), level >= 1 */
+pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc mg, int32_t level, int32_t nrows, int32_t ncols, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host);
 /* -mg_levels_pc_type sorgibbs (scaled = 0, omega = 1) | mcgibbs (scaled = 1, any omega, any sweep type);
    its = -mg_levels_ksp_max_it */
 pmg_status pmg_mgmc_set_smoother(pmg_mgmc mg, int scaled, double omega, int sweep_type, int32_t its);

@@ -106,6 +106,9 @@ _sig = {
     "pmg_chol_sample": (_int, [_vp, _vp, _vp, _int, _u64, _u64, _vp]),
     "pmg_chol_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_mgmc_create_dmda": (_int, [_i32, _i32, _i32, _dbl, _i32, C.POINTER(_vp)]),
+    "pmg_mgmc_create_hierarchy": (_int, [_i32, C.POINTER(_vp)]),
+    "pmg_mgmc_set_level_operator": (_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "pmg_mgmc_set_level_interpolation": (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pmg_mgmc_set_smoother": (_int, [_vp, _int, _dbl, _int, _i32]),
     "pmg_mgmc_set_coarse": (_int, [_vp, _int, _i32]),
     "pmg_mgmc_set_keep_host": (_int, [_vp, _int]),

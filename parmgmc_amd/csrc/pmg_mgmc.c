@@ -45,6 +45,8 @@ typedef struct {
   double  *P_val, *R_val;
   /* optional host copies (natural numbering) for inspection */
   hcsr A_host, P_host;
+  /* caller-supplied hierarchy (borrowed host CSR until set-up) */
+  hcsr A_user, P_user;
 } mg_level;
 
 struct pmg_mgmc_s {
@@ -53,7 +55,7 @@ struct pmg_mgmc_s {
   double    kappa, omega;
   int       nu, scaled, sweep_type;
   int       coarse_type, coarse_its; /* 0 = cholsampler, 1 = Gibbs sweeps */
-  int       keep_host, is_setup;
+  int       keep_host, is_setup, user_hier;
   pmg_chol  chol;
   double   *y_lay, *b_lay;
 };
@@ -274,6 +276,64 @@ pmg_status pmg_mgmc_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa
   return PMG_SUCCESS;
 }
 
+/* A hierarchy handed over level by level: what PCGAMGMC finds inside PETSc's PCMG/PCGAMG after PCSetUp -- the
+   level operators (PCMGGetSmoother + PCGetOperators) and interpolations (PCMGGetInterpolation), reference
+   src/pc_gamgmc.c:165-176 -- e.g. a GAMG hierarchy of an unstructured P1 matrix.  Every level is swept with the
+   sliced-ELL multicolour kernel (greedy colouring), transfers are CSR products. */
+pmg_status pmg_mgmc_create_hierarchy(int32_t levels, pmg_mgmc *out)
+{
+  PMG_CHECK(out, PMG_ERR_ARG_NULL, "null output handle");
+  *out = NULL;
+  PMG_CHECK(levels >= 2 && levels <= 64, PMG_ERR_ARG_OUTOFRANGE, "levels = %d", levels);
+  pmg_mgmc h = (pmg_mgmc)calloc(1, sizeof *h);
+  PMG_CHECK(h, PMG_ERR_MEM, "out of host memory");
+  h->lv = (mg_level *)calloc((size_t)levels, sizeof(mg_level));
+  if (!h->lv) {
+    free(h);
+    PMG_FAIL(PMG_ERR_MEM, "out of host memory");
+  }
+  h->nlevels     = levels;
+  h->user_hier   = 1;
+  h->omega       = 1.0;
+  h->nu          = 1;
+  h->scaled      = 0;
+  h->sweep_type  = PMG_SOR_FORWARD_SWEEP;
+  h->coarse_type = 0;
+  h->coarse_its  = 1;
+  *out           = h;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_set_level_operator(pmg_mgmc h, int32_t level, int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals)
+{
+  PMG_CHECK(h && rowptr && colidx && vals, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(h->user_hier && !h->is_setup, PMG_ERR_ARG_WRONGSTATE, "level operators belong to pmg_mgmc_create_hierarchy, before set-up");
+  PMG_CHECK(level >= 0 && level < h->nlevels && n >= 1, PMG_ERR_ARG_OUTOFRANGE, "level %d, n %d", level, n);
+  mg_level *Lv = &h->lv[level];
+  Lv->n        = n;
+  Lv->nx       = n;
+  Lv->ny = Lv->nz = 1;
+  Lv->A_user.nr = Lv->A_user.nc = n;
+  Lv->A_user.rp = (int32_t *)rowptr; /* borrowed, only read */
+  Lv->A_user.ci = (int32_t *)colidx;
+  Lv->A_user.v  = (double *)vals;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc h, int32_t level, int32_t nrows, int32_t ncols, const int32_t *rowptr, const int32_t *colidx, const double *vals)
+{
+  PMG_CHECK(h && rowptr && colidx && vals, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(h->user_hier && !h->is_setup, PMG_ERR_ARG_WRONGSTATE, "interpolations belong to pmg_mgmc_create_hierarchy, before set-up");
+  PMG_CHECK(level >= 1 && level < h->nlevels, PMG_ERR_ARG_OUTOFRANGE, "level %d", level);
+  mg_level *Lv  = &h->lv[level];
+  Lv->P_user.nr = nrows;
+  Lv->P_user.nc = ncols;
+  Lv->P_user.rp = (int32_t *)rowptr;
+  Lv->P_user.ci = (int32_t *)colidx;
+  Lv->P_user.v  = (double *)vals;
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_mgmc_set_smoother(pmg_mgmc h, int scaled, double omega, int sweep_type, int32_t its)
 {
   PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
@@ -323,10 +383,67 @@ static pmg_status upload_transfer(const hcsr *M, const int32_t *rowpos_of, const
   return st;
 }
 
+static pmg_status upload_transfer(const hcsr *M, const int32_t *rowpos_of, const int32_t *colpos_of, int32_t **rowpos, int32_t **rowptr, int32_t **col, double **val);
+
+static pmg_status mgmc_setup_user(pmg_mgmc h)
+{
+  const int top = h->nlevels - 1;
+  int32_t **pos = (int32_t **)calloc((size_t)h->nlevels, sizeof(int32_t *));
+  PMG_CHECK(pos, PMG_ERR_MEM, "out of host memory");
+  for (int l = 0; l <= top; ++l) {
+    mg_level *Lv = &h->lv[l];
+    PMG_CHECK(Lv->A_user.rp, PMG_ERR_ARG_WRONGSTATE, "level %d has no operator", l);
+    PMG_CHECK(l == 0 || (Lv->P_user.rp && Lv->P_user.nr == Lv->n && Lv->P_user.nc == h->lv[l - 1].n), PMG_ERR_ARG_SIZ, "interpolation of level %d missing or of the wrong shape", l);
+    pos[l] = (int32_t *)malloc(sizeof(int32_t) * (size_t)Lv->n);
+    PMG_CHECK(pos[l], PMG_ERR_MEM, "out of host memory");
+    if (l > 0 || h->coarse_type == 1) {
+      PMG_CALL(pmg_mcsor_create_csr(Lv->n, Lv->A_user.rp, Lv->A_user.ci, Lv->A_user.v, &Lv->mc));
+      PMG_CALL(pmg_mcsor_set_coloring(Lv->mc, PMG_COLORING_GREEDY, NULL));
+      PMG_CALL(pmg_mcsor_set_omega(Lv->mc, h->omega));
+      PMG_CALL(pmg_mcsor_set_sweep_type(Lv->mc, h->sweep_type));
+      PMG_CALL(pmg_mcsor_setup(Lv->mc));
+      int32_t ld32;
+      PMG_CALL(pmg_mcsor_layout_len(Lv->mc, &ld32));
+      Lv->ld = ld32;
+      PMG_CALL(pmg_mcsor_get_layout(Lv->mc, pos[l]));
+    } else {
+      Lv->ld = Lv->n;
+      for (int32_t q = 0; q < Lv->n; ++q) pos[l][q] = q;
+    }
+    if (l == 0 && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr(Lv->n, Lv->A_user.rp, Lv->A_user.ci, Lv->A_user.v, &h->chol));
+  }
+  for (int l = 1; l <= top; ++l) {
+    mg_level *U = &h->lv[l];
+    hcsr      R;
+    memset(&R, 0, sizeof R);
+    PMG_CALL(hcsr_transpose(&U->P_user, &R));
+    U->P_nrows = U->P_user.nr;
+    U->R_nrows = R.nr;
+    PMG_CALL(upload_transfer(&U->P_user, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
+    PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    hcsr_free(&R);
+  }
+  for (int l = 0; l <= top; ++l) {
+    free(pos[l]);
+    mg_level *Lv = &h->lv[l];
+    memset(&Lv->A_user, 0, sizeof Lv->A_user); /* borrowed arrays are released */
+    memset(&Lv->P_user, 0, sizeof Lv->P_user);
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->b, sizeof(double) * (size_t)Lv->ld));
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->x, sizeof(double) * (size_t)Lv->ld));
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->r, sizeof(double) * (size_t)Lv->ld));
+  }
+  free(pos);
+  PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)h->lv[top].ld));
+  PMG_CALL(pmg_dev_alloc((void **)&h->b_lay, sizeof(double) * (size_t)h->lv[top].ld));
+  h->is_setup = 1;
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_mgmc_setup(pmg_mgmc h)
 {
   PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
   if (h->is_setup) return PMG_SUCCESS;
+  if (h->user_hier) return mgmc_setup_user(h);
   const int top = h->nlevels - 1;
   /* finest level: matrix-free grid operator */
   mg_level *F = &h->lv[top];
@@ -534,6 +651,15 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, void *st
   return PMG_SUCCESS;
 }
 
+static pmg_status lvl_to_layout(mg_level *Lv, const double *nat, double *lay, void *stream)
+{
+  return Lv->is_grid ? pmg_grid_to_cvec(Lv->g, nat, lay, stream) : pmg_mcsor_to_layout(Lv->mc, nat, lay, stream);
+}
+static pmg_status lvl_from_layout(mg_level *Lv, const double *lay, double *nat, void *stream)
+{
+  return Lv->is_grid ? pmg_grid_from_cvec(Lv->g, lay, nat, stream) : pmg_mcsor_from_layout(Lv->mc, lay, nat, stream);
+}
+
 pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32_t its, int guesszero, uint64_t seed, uint64_t counter0, uint64_t *counter_out, pmg_sample_callback cb, void *cbctx, void *stream)
 {
   PMG_CHECK(h && b_nat && y_nat, PMG_ERR_ARG_NULL, "null argument");
@@ -541,25 +667,26 @@ pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32
   PMG_CHECK(its >= 0, PMG_ERR_ARG_OUTOFRANGE, "its = %d", its);
   mg_level    *F     = &h->lv[h->nlevels - 1];
   const size_t bytes = sizeof(double) * (size_t)F->ld;
-  PMG_CALL(pmg_grid_to_cvec(F->g, b_nat, h->b_lay, stream));
-  PMG_CALL(pmg_grid_to_cvec(F->g, y_nat, h->y_lay, stream));
+  PMG_CALL(lvl_to_layout(F, b_nat, h->b_lay, stream));
+  PMG_CALL(lvl_to_layout(F, y_nat, h->y_lay, stream));
   for (int32_t it = 0; it < its; ++it) {
     if (it == 0 && guesszero) { /* y = MG(b), src/pc_gamgmc.c:243-246 */
       PMG_HIP(hipMemcpyAsync(F->b, h->b_lay, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
       PMG_CALL(mg_vcycle(h, seed, counter0 + (uint64_t)it, stream));
       PMG_HIP(hipMemcpyAsync(h->y_lay, F->x, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     } else { /* w = b - A y; work = MG(w); y += work, src/pc_gamgmc.c:253-256 */
-      PMG_CALL(pmg_grid_residual_cvec(F->g, h->b_lay, h->y_lay, F->b, stream));
+      if (F->is_grid) PMG_CALL(pmg_grid_residual_cvec(F->g, h->b_lay, h->y_lay, F->b, stream));
+      else PMG_CALL(pmg_mcsor_residual_layout(F->mc, h->b_lay, h->y_lay, F->b, stream));
       PMG_CALL(mg_vcycle(h, seed, counter0 + (uint64_t)it, stream));
       PMG_KERNEL(pmgk_axpy(F->ld, 1.0, F->x, h->y_lay, stream));
     }
     if (cb) { /* pg->scb(it, y, ctx), src/pc_gamgmc.c:258 */
-      PMG_CALL(pmg_grid_from_cvec(F->g, h->y_lay, y_nat, stream));
+      PMG_CALL(lvl_from_layout(F, h->y_lay, y_nat, stream));
       const int rc = cb(it, y_nat, F->n, cbctx);
       PMG_CHECK(rc == 0, rc, "sample callback returned %d", rc);
     }
   }
-  PMG_CALL(pmg_grid_from_cvec(F->g, h->y_lay, y_nat, stream));
+  PMG_CALL(lvl_from_layout(F, h->y_lay, y_nat, stream));
   if (counter_out) *counter_out = counter0 + (uint64_t)its;
   return PMG_SUCCESS;
 }

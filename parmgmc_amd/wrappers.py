@@ -224,6 +224,28 @@ class MGMC:
         check(lib.pmg_mgmc_set_keep_host(self._h, int(keep_host)))
         self.levels = levels
 
+    @classmethod
+    def from_hierarchy(cls, operators, interpolations):
+        """operators[l] = (rowptr, colidx, vals) of level l (0 = coarsest); interpolations[l] (l >= 1) = CSR triple of
+        the prolongation from level l-1 to level l (reference src/pc_gamgmc.c:165-176: what PCMG holds)."""
+        self = cls.__new__(cls)
+        levels = len(operators)
+        self._h = C.c_void_p()
+        self.levels = levels
+        self._keep = []
+        check(lib.pmg_mgmc_create_hierarchy(levels, C.byref(self._h)))
+        for l, (rp, ci, v) in enumerate(operators):
+            rp, ci, v = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(v, np.float64)
+            self._keep.append((rp, ci, v))
+            check(lib.pmg_mgmc_set_level_operator(self._h, l, len(rp) - 1, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+        for l in range(1, levels):
+            rp, ci, v = interpolations[l]
+            rp, ci, v = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(v, np.float64)
+            self._keep.append((rp, ci, v))
+            check(lib.pmg_mgmc_set_level_interpolation(self._h, l, len(rp) - 1, len(operators[l - 1][0]) - 1, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+        self.n = len(operators[-1][0]) - 1
+        return self
+
     def set_smoother(self, scaled: bool, omega: float = 1.0, sweep_type: int = capi.SOR_FORWARD_SWEEP, its: int = 1):
         check(lib.pmg_mgmc_set_smoother(self._h, int(scaled), omega, sweep_type, its))
 
