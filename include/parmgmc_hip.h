@@ -110,6 +110,12 @@ pmg_status pmg_mcsor_from_layout(pmg_mcsor mc, const double *lay_dev, double *na
 pmg_status pmg_mcsor_apply_layout(pmg_mcsor mc, const double *b_lay, double *y_lay, void *stream);
 pmg_status pmg_mcsor_sample_layout(pmg_mcsor mc, const double *b_lay, double *y_lay, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
 pmg_status pmg_mcsor_residual_layout(pmg_mcsor mc, const double *b_lay, const double *y_lay, double *r_lay, void *stream);
+/* MATLRC operators A + B S B^T (MCSORSetUp's LRC branch, src/mc_sor.c:572-595; MCSORBuildLRCCorrection :480-544):
+   B is n x k column-major on the host in the matrix's row numbering, S the k diagonal entries of Sigma^-1.
+   Call after pmg_mcsor_setup (uses the current omega).  Afterwards every directional sweep is followed by
+   y -= Bb (B^T y) (:101-112) and every noisy right-hand side gets + B (sqrt(S) o eta) (src/pc_mcgibbs.c:130-140,
+   src/pc_sorgibbs.c:86-90).  k = 0 removes the update. */
+pmg_status pmg_mcsor_set_lowrank(pmg_mcsor mc, int32_t k, const double *B_host, const double *S_host);
 /* MCSORDestroy (src/mc_sor.c:60-90); *mc = NULL afterwards; NULL handle is a no-op. */
 pmg_status pmg_mcsor_destroy(pmg_mcsor *mc);
 
@@ -156,6 +162,8 @@ pmg_status pmg_grid_sweep_color_planes_cvec(pmg_grid g, int color, int32_t kbegi
    receives the neighbour's plane.  A plane of one colour is one contiguous block, so the exchange that replaces
    the reference's per-colour VecScatter (src/mc_sor.c:318-319) is a single contiguous send/recv. */
 pmg_status pmg_grid_halo_plane(pmg_grid g, int color, int side, int64_t *owned_offset, int64_t *ghost_offset, int64_t *count);
+/* the same MATLRC update for the grid operator (B in DMDA natural order); single-device grids */
+pmg_status pmg_grid_set_lowrank(pmg_grid g, int32_t k, const double *B_host, const double *S_host);
 /* Sample loop on natural-order vectors: converts in once, runs `its` sweeps, converts out once. */
 pmg_status pmg_grid_sample(pmg_grid g, const double *b_nat_dev, double *y_nat_dev, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
 pmg_status pmg_grid_destroy(pmg_grid *g);

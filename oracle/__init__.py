@@ -469,3 +469,45 @@ def chol_sample(L: np.ndarray, x: np.ndarray, xi: np.ndarray) -> np.ndarray:
     y = np.zeros(n)
     lib().orc_chol_sample(n, flat, np.ascontiguousarray(x, np.float64), np.ascontiguousarray(xi, np.float64), y)
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# low-rank updates (MATLRC): A_post = A + B diag(S) B^T
+# ------------------------------------------------------------------------------------------------
+def lrc_build_correction(A: CSR, colors, B: np.ndarray, S: np.ndarray, omega: float, direction: int) -> np.ndarray:
+    """MCSORBuildLRCCorrection (reference src/mc_sor.c:480-544): C = M_A^-1 B column by column with one
+    deterministic sweep from a zero guess (:499-510), T = B^T C + S^-1 (:514-527), Sb = T^-1 (:528-533),
+    Bb = C Sb (:535)."""
+    n, k = B.shape
+    Cm = np.stack([mcsor_apply(A, colors, B[:, i], np.zeros(n), omega, direction) for i in range(k)], 1)
+    T = B.T @ Cm + np.diag(1.0 / S)
+    return Cm @ np.linalg.inv(T)
+
+
+def lrc_mcsor_apply(A: CSR, colors, B, Bb_f, Bb_b, b, y, omega=1.0, sweep=SOR_FORWARD) -> np.ndarray:
+    """MCSORApply on a MATLRC operator (reference src/mc_sor.c:216-239 with postsor = MCSORPostSOR_LRC :101-112):
+    every directional sweep is followed by y -= Bb (B^T y)."""
+    dirs = [SOR_FORWARD, SOR_BACKWARD] if sweep == SOR_SYMMETRIC else [sweep]
+    for d in dirs:
+        y = mcsor_apply(A, colors, b, y, omega, d)
+        Bb = Bb_f if d == SOR_FORWARD else Bb_b
+        y = y - Bb @ (B.T @ y)
+    return y
+
+
+def lrc_gibbs_samples(A: CSR, colors, B, S, b, y0, its, noise_fn, eta_fn, omega=1.0, sweep=SOR_FORWARD, scaled=True) -> np.ndarray:
+    """PCApplyRichardson_MulticolorGibbs with prepare_rhs = PrepareRHS_LRC (reference src/pc_mcgibbs.c:130-140,
+    :155-188) / PCSORGibbsSample's LRC branch (src/pc_sorgibbs.c:86-101): w = xi*sqrtdiag + b + B (sqrt(S) o eta),
+    sweep on A, then y -= Bb (B^T y).  noise_fn(draw) -> xi (N), eta_fn(draw) -> eta (k)."""
+    Bb_f = lrc_build_correction(A, colors, B, S, omega, SOR_FORWARD)
+    Bb_b = lrc_build_correction(A, colors, B, S, omega, SOR_BACKWARD)
+    sd = sqrtdiag(A, omega, scaled)
+    sqrtS = np.sqrt(np.abs(S))
+    y = np.array(y0, np.float64, copy=True)
+    draw = 0
+    for _ in range(its):
+        for d in ([SOR_FORWARD, SOR_BACKWARD] if sweep == SOR_SYMMETRIC else [sweep]):
+            w = prepare_rhs(noise_fn(draw), sd, b) + B @ (sqrtS * eta_fn(draw))
+            draw += 1
+            y = lrc_mcsor_apply(A, colors, B, Bb_f, Bb_b, w, y, omega, d)
+    return y

@@ -81,6 +81,7 @@ _sig = {
     "pmg_mcsor_apply_layout": (_int, [_vp, _vp, _vp, _vp]),
     "pmg_mcsor_sample_layout": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_mcsor_residual_layout": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pmg_mcsor_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_mcsor_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_grid_create": (_int, [_i32, _i32, _i32, _i32, _i32, _dbl, C.POINTER(_vp)]),
     "pmg_grid_set_omega": (_int, [_vp, _dbl]),
@@ -99,6 +100,7 @@ _sig = {
     "pmg_grid_sweep_color_cvec": (_int, [_vp, _int, _int, _int, _u64, _u64, _vp, _vp, _vp]),
     "pmg_grid_sweep_color_planes_cvec": (_int, [_vp, _int, _i32, _i32, _int, _int, _u64, _u64, _vp, _vp, _vp]),
     "pmg_grid_halo_plane": (_int, [_vp, _int, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "pmg_grid_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_grid_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_grid_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_chol_create_csr": (_int, [_i32, _vp, _vp, _vp, C.POINTER(_vp)]),

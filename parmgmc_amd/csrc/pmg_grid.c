@@ -16,6 +16,7 @@ struct pmg_grid_s {
   int              type;
   double           diag[8], idiag[8], sqrtd[8];
   double          *b_cv, *y_cv; /* scratch cvecs for the natural-order entry points */
+  pmg_lrc          lrc;         /* MATLRC: rank-k update B S B^T (src/mc_sor.c:572-595) */
 };
 
 /* idiag = (1/d)*omega (MCSORUpdateIDiag, src/mc_sor.c:114-124) and sqrt|d| (VecSqrtAbs, src/pc_mcgibbs.c:149) */
@@ -68,6 +69,7 @@ pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L)
 pmg_status pmg_grid_destroy(pmg_grid *g)
 {
   if (!g || !*g) return PMG_SUCCESS;
+  pmg_lrc_destroy(&(*g)->lrc);
   pmg_dev_free((*g)->b_cv);
   pmg_dev_free((*g)->y_cv);
   free(*g);
@@ -168,15 +170,47 @@ static void pmg_grid_fill_op(pmg_grid g, pmgk_grid_op *op, int noisy, int scaled
   op->omega_is_one = g->omega == 1.0;
 }
 
-/* One forward (colours 0,1) or backward (colours 1,0; src/mc_sor.c:274) sweep. */
+/* One forward (colours 0,1) or backward (colours 1,0; src/mc_sor.c:274) sweep, with the low-rank noise term and
+   repair (src/pc_mcgibbs.c:130-140, src/mc_sor.c:101-112) when a MATLRC update is attached. */
 static pmg_status pmg_grid_one_sweep(pmg_grid g, int dir, int noisy, int scaled, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream)
 {
+  if (g->lrc && noisy) PMG_CALL(pmg_lrc_rhs(g->lrc, b, seed, sweep, &b, stream));
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, noisy, scaled, seed, sweep);
   const int c0 = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
   PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, b, y, stream));
   PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, b, y, stream));
+  if (g->lrc) PMG_CALL(pmg_lrc_post(g->lrc, dir, y, stream));
   return PMG_SUCCESS;
+}
+
+static pmg_status grid_det_sweep(void *ctx, int dir, const double *b, double *y, void *stream)
+{
+  pmg_grid     g = (pmg_grid)ctx;
+  pmgk_grid_op op;
+  pmg_grid_fill_op(g, &op, 0, 0, 0, 0);
+  const int c0 = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, b, y, stream));
+  return PMG_SUCCESS;
+}
+
+/* MCSORSetUp's MATLRC branch (src/mc_sor.c:572-595) for the grid operator: B is (nx*ny*nz) x k column-major in
+   DMDA natural order, S the k diagonal entries of Sigma^-1.  Uses the CURRENT omega.  k = 0 removes the update.
+   Single-device grids only (the dense B^T y reduction over devices is not built). */
+pmg_status pmg_grid_set_lowrank(pmg_grid g, int32_t k, const double *B_host, const double *S_host)
+{
+  PMG_CHECK(g, PMG_ERR_ARG_NULL, "null grid");
+  PMG_CHECK(g->L.nz == g->L.nzg, PMG_ERR_SUP, "low-rank updates are single-device");
+  pmg_lrc_destroy(&g->lrc);
+  if (k == 0) return PMG_SUCCESS;
+  const int64_t n   = (int64_t)g->L.nx * g->L.ny * g->L.nz;
+  int64_t      *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+  PMG_CHECK(pos, PMG_ERR_MEM, "out of host memory");
+  pmg_status st = pmg_grid_get_layout(g, pos);
+  if (!st) st = pmg_lrc_build(&g->lrc, k, 2 * g->L.cs, (int32_t)n, B_host, pos, S_host, grid_det_sweep, g);
+  free(pos);
+  return st;
 }
 
 pmg_status pmg_grid_sweep_color_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const double *b, double *y, void *stream)

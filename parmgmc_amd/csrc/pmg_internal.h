@@ -41,6 +41,14 @@ static inline int pmg_sweep_type_ok(int t) { return t == PMG_SOR_FORWARD_SWEEP |
 /* kernel-side description of a grid object (internal) */
 pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L);
 
+/* low-rank (MATLRC) helper shared by pmg_mcsor and pmg_grid (pmg_lrc.c); vectors in the sampler's layout */
+typedef struct pmg_lrc_s *pmg_lrc;
+typedef pmg_status (*pmg_det_sweep_fn)(void *ctx, int dir, const double *b_lay, double *y_lay, void *stream);
+pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const double *B_nat_host, const int64_t *pos, const double *S_host, pmg_det_sweep_fn det, void *ctx);
+pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t counter, const double **beff, void *stream);
+pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
+void       pmg_lrc_destroy(pmg_lrc *l);
+
 /* device allocation helpers (zero-filled) */
 pmg_status pmg_dev_alloc(void **p, size_t bytes);
 pmg_status pmg_dev_upload(void **p, const void *host, size_t bytes);

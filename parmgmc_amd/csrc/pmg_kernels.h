@@ -84,6 +84,12 @@ int pmgk_potrf_inverse(int32_t npad, double *A_colmajor, double *W_colmajor, dou
 int pmgk_pack_rowmajor(int32_t n, const double *in_colmajor, int64_t ld, int transpose, double *out_rowmajor, void *stream);
 /* triangular matrix-vector products of the coarse exact sampler (row-major n x n, lower or upper part) */
 int pmgk_tri_gemv(int32_t n, int upper, const double *M, const double *x, const double *add, double *out, void *stream);
+/* low-rank (MATLRC) pieces: M is n x k column-major with leading dimension ld, k <= 64 */
+int pmgk_lrc_nblocks(int64_t n);
+int pmgk_lrc_btx(int64_t n, int k, const double *M, int64_t ld, const double *y, double *partial, const double *scale, double *out, void *stream);
+int pmgk_lrc_axpy_cols(int64_t n, int k, const double *M, int64_t ld, const double *coef, double sign, const double *in, double *out, void *stream);
+int pmgk_lrc_gemm_small(int64_t n, int k, const double *Cm, int64_t ld, const double *Sb, double *Bb, void *stream);
+int pmgk_lrc_mul(int k, const double *a, const double *b, double *out, void *stream);
 int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);
 int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream);
 

@@ -1,0 +1,157 @@
+/* Low-rank (MATLRC) support of the samplers -- host side (C11).
+ *
+ * For a precision A_post = A + B S B^T (B dense N x k, S = Sigma^-1 diagonal; Bayesian update with k observations)
+ * the reference sweeps on the base matrix A and repairs every sweep with a rank-k Woodbury correction:
+ *   - set-up, MCSORBuildLRCCorrection (src/mc_sor.c:480-544): C = M_A^-1 B column by column with ONE deterministic
+ *     sweep from a zero guess per column (:499-510), T = B^T C + S^-1 (:514-527), Sb = T^-1 (:528-533),
+ *     Bb = C Sb (:535); one Bb per sweep direction (src/mc_sor.c:578-590);
+ *   - after every directional sweep, MCSORPostSOR_LRC (src/mc_sor.c:101-112): y -= Bb (B^T y);
+ *   - the noisy right-hand side gets the extra term B (sqrt(S) o eta), eta ~ N(0, I_k):
+ *     PrepareRHS_LRC (src/pc_mcgibbs.c:130-140), PCSORGibbsSample (src/pc_sorgibbs.c:86-90).
+ * All N x k operands live on the device in the sampler's storage layout; the k x k inverse is formed on the host
+ * (exact LU; the reference's KSPMatSolve on a k x k system converges to machine precision in <= k GMRES steps).
+ */
+#include "pmg_internal.h"
+#include <math.h>
+
+struct pmg_lrc_s {
+  int      k;
+  int64_t  ld;
+  double  *B, *Bb[2]; /* device, ld x k column-major; Bb[0] forward, Bb[1] backward */
+  double  *S, *sqrtS; /* device, k */
+  double  *wk, *eta, *partial, *beff, *col; /* device work space */
+};
+
+void pmg_lrc_destroy(pmg_lrc *p)
+{
+  if (!p || !*p) return;
+  pmg_lrc l = *p;
+  pmg_dev_free(l->B);
+  pmg_dev_free(l->Bb[0]);
+  pmg_dev_free(l->Bb[1]);
+  pmg_dev_free(l->S);
+  pmg_dev_free(l->sqrtS);
+  pmg_dev_free(l->wk);
+  pmg_dev_free(l->eta);
+  pmg_dev_free(l->partial);
+  pmg_dev_free(l->beff);
+  pmg_dev_free(l->col);
+  free(l);
+  *p = NULL;
+}
+
+/* in-place inverse of a small dense matrix (column-major k x k) by Gauss-Jordan with partial pivoting */
+static int invert_small(int k, double *a, double *inv)
+{
+  for (int i = 0; i < k * k; ++i) inv[i] = 0.0;
+  for (int i = 0; i < k; ++i) inv[i + k * i] = 1.0;
+  for (int c = 0; c < k; ++c) {
+    int    piv = c;
+    double mx  = fabs(a[c + k * c]);
+    for (int r = c + 1; r < k; ++r)
+      if (fabs(a[r + k * c]) > mx) {
+        mx  = fabs(a[r + k * c]);
+        piv = r;
+      }
+    if (mx == 0.0) return 1;
+    if (piv != c)
+      for (int j = 0; j < k; ++j) {
+        double t = a[c + k * j]; a[c + k * j] = a[piv + k * j]; a[piv + k * j] = t;
+        t = inv[c + k * j]; inv[c + k * j] = inv[piv + k * j]; inv[piv + k * j] = t;
+      }
+    const double d = 1.0 / a[c + k * c];
+    for (int j = 0; j < k; ++j) {
+      a[c + k * j] *= d;
+      inv[c + k * j] *= d;
+    }
+    for (int r = 0; r < k; ++r)
+      if (r != c) {
+        const double f = a[r + k * c];
+        if (f != 0.0)
+          for (int j = 0; j < k; ++j) {
+            a[r + k * j] -= f * a[c + k * j];
+            inv[r + k * j] -= f * inv[c + k * j];
+          }
+      }
+  }
+  return 0;
+}
+
+pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const double *B_nat_host, const int64_t *pos, const double *S_host, pmg_det_sweep_fn det, void *ctx)
+{
+  PMG_CHECK(out && B_nat_host && pos && S_host && det, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(k >= 1 && k <= 64, PMG_ERR_ARG_OUTOFRANGE, "rank k = %d (1..64 supported)", k);
+  *out      = NULL;
+  pmg_lrc l = (pmg_lrc)calloc(1, sizeof *l);
+  PMG_CHECK(l, PMG_ERR_MEM, "out of host memory");
+  l->k  = k;
+  l->ld = ld;
+  /* B in layout order */
+  double *Bl = (double *)calloc((size_t)ld * k, sizeof(double));
+  double *sq = (double *)malloc(sizeof(double) * (size_t)k);
+  if (!Bl || !sq) {
+    free(Bl); free(sq); free(l);
+    PMG_FAIL(PMG_ERR_MEM, "out of host memory");
+  }
+  for (int c = 0; c < k; ++c)
+    for (int32_t r = 0; r < n; ++r) Bl[pos[r] + ld * c] = B_nat_host[r + (size_t)n * c];
+  for (int c = 0; c < k; ++c) sq[c] = sqrt(fabs(S_host[c])); /* VecSqrtAbs(sqrtS), src/pc_mcgibbs.c:240-242 */
+  pmg_status st = pmg_dev_upload((void **)&l->B, Bl, sizeof(double) * (size_t)ld * k);
+  free(Bl);
+  if (!st) st = pmg_dev_upload((void **)&l->S, S_host, sizeof(double) * (size_t)k);
+  if (!st) st = pmg_dev_upload((void **)&l->sqrtS, sq, sizeof(double) * (size_t)k);
+  free(sq);
+  for (int d = 0; d < 2 && !st; ++d) st = pmg_dev_alloc((void **)&l->Bb[d], sizeof(double) * (size_t)ld * k);
+  if (!st) st = pmg_dev_alloc((void **)&l->wk, sizeof(double) * 64);
+  if (!st) st = pmg_dev_alloc((void **)&l->eta, sizeof(double) * 64);
+  if (!st) st = pmg_dev_alloc((void **)&l->partial, sizeof(double) * (size_t)pmgk_lrc_nblocks(ld) * k);
+  if (!st) st = pmg_dev_alloc((void **)&l->beff, sizeof(double) * (size_t)ld);
+  if (!st) st = pmg_dev_alloc((void **)&l->col, sizeof(double) * (size_t)ld * k); /* C = M_A^-1 B */
+  double *T = (double *)malloc(sizeof(double) * (size_t)k * k), *Sb = (double *)malloc(sizeof(double) * (size_t)k * k), *Sb_dev = NULL;
+  if (!st && (!T || !Sb)) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+  if (!st) st = pmg_dev_alloc((void **)&Sb_dev, sizeof(double) * (size_t)k * k);
+  for (int d = 0; d < 2 && !st; ++d) {
+    const int dir = d == 0 ? PMG_SOR_FORWARD_SWEEP : PMG_SOR_BACKWARD_SWEEP;
+    for (int c = 0; c < k && !st; ++c) { /* C(:,c) = one deterministic sweep on B(:,c) from x = 0, src/mc_sor.c:499-510 */
+      if (hipMemsetAsync(l->col + ld * c, 0, sizeof(double) * (size_t)ld, NULL) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+      if (!st) st = det(ctx, dir, l->B + ld * c, l->col + ld * c, NULL);
+    }
+    for (int c = 0; c < k && !st; ++c) { /* T(:,c) = B^T C(:,c), src/mc_sor.c:514 */
+      if (pmgk_lrc_btx(ld, k, l->B, ld, l->col + ld * c, l->partial, NULL, l->wk, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
+      if (!st && hipMemcpy(T + (size_t)k * c, l->wk, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
+    }
+    if (st) break;
+    for (int c = 0; c < k; ++c) T[c + (size_t)k * c] += 1.0 / S_host[c]; /* + S^-1, src/mc_sor.c:525-527 */
+    if (invert_small(k, T, Sb)) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "S^-1 + B^T M^-1 B is singular");
+    if (!st && hipMemcpy(Sb_dev, Sb, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "upload failed");
+    if (!st && pmgk_lrc_gemm_small(ld, k, l->col, ld, Sb_dev, l->Bb[d], NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed"); /* Bb = C Sb, :535 */
+    if (!st && hipDeviceSynchronize() != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device error while building the low-rank correction");
+  }
+  free(T);
+  free(Sb);
+  pmg_dev_free(Sb_dev);
+  if (st) {
+    pmg_lrc_destroy(&l);
+    return st;
+  }
+  *out = l;
+  return PMG_SUCCESS;
+}
+
+/* b_eff = b + B (sqrt(S) o eta), eta = row-stream normals of (seed + tag, counter); returns the device vector */
+pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t counter, const double **beff, void *stream)
+{
+  PMG_KERNEL(pmgk_fill_normal_rows(l->k, seed + 0x632BE59BD9B4E019ull, counter, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w) */
+  PMG_KERNEL(pmgk_lrc_mul(l->k, l->eta, l->sqrtS, l->eta, stream));                               /* VecPointwiseMult(w, w, sqrtS)   */
+  PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->B, l->ld, l->eta, 1.0, b_lay, l->beff, stream));  /* MatMultAdd(B, w, rhs, rhs)      */
+  *beff = l->beff;
+  return PMG_SUCCESS;
+}
+
+/* y -= Bb_dir (B^T y), src/mc_sor.c:101-112 */
+pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
+{
+  PMG_KERNEL(pmgk_lrc_btx(l->ld, l->k, l->B, l->ld, y_lay, l->partial, NULL, l->wk, stream));
+  PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->Bb[dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1], l->ld, l->wk, -1.0, y_lay, y_lay, stream));
+  return PMG_SUCCESS;
+}

@@ -31,6 +31,7 @@ struct pmg_mcsor_s {
   pmgk_sell S;         /* device arrays */
   double  *idiag_dev, *sqrtd_dev, *sqrtd_scaled_dev;
   double  *b_p, *y_p, *r_p; /* permuted scratch vectors */
+  pmg_lrc  lrc;             /* MATLRC: rank-k update B S B^T (src/mc_sor.c:572-595) */
 };
 
 /* --- colouring rules -------------------------------------------------------------------------------- */
@@ -370,6 +371,17 @@ static pmg_status mcsor_one_sweep(pmg_mcsor mc, int dir, int noisy, int scaled, 
   return PMG_SUCCESS;
 }
 
+/* one directional sweep + the low-rank repair: ctx->sor(...) then ctx->postsor(...) of src/mc_sor.c:223-236, with
+   the extra noise term of PrepareRHS_LRC (src/pc_mcgibbs.c:130-140) when the sweep is a noisy one */
+static pmg_status mcsor_sweep_lrc(pmg_mcsor mc, int dir, int noisy, int scaled, uint64_t seed, uint64_t sweep, const double *b_p, double *y_p, void *stream)
+{
+  const double *rhs = b_p;
+  if (mc->lrc && noisy) PMG_CALL(pmg_lrc_rhs(mc->lrc, b_p, seed, sweep, &rhs, stream));
+  PMG_CALL(mcsor_one_sweep(mc, dir, noisy, scaled, seed, sweep, rhs, y_p, stream));
+  if (mc->lrc) PMG_CALL(pmg_lrc_post(mc->lrc, dir, y_p, stream));
+  return PMG_SUCCESS;
+}
+
 static pmg_status mcsor_ready(pmg_mcsor mc)
 {
   PMG_CHECK(mc->is_setup, PMG_ERR_ARG_WRONGSTATE, "call pmg_mcsor_setup first");
@@ -384,10 +396,10 @@ pmg_status pmg_mcsor_apply(pmg_mcsor mc, const double *b, double *y, void *strea
   PMG_KERNEL(pmgk_permute_in(mc->S.ld, mc->S.orig, b, mc->b_p, stream));
   PMG_KERNEL(pmgk_permute_in(mc->S.ld, mc->S.orig, y, mc->y_p, stream));
   if (mc->type == PMG_SOR_SYMMETRIC_SWEEP) { /* src/mc_sor.c:223-232 */
-    PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_FORWARD_SWEEP, 0, 0, 0, 0, mc->b_p, mc->y_p, stream));
-    PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_BACKWARD_SWEEP, 0, 0, 0, 0, mc->b_p, mc->y_p, stream));
+    PMG_CALL(mcsor_sweep_lrc(mc, PMG_SOR_FORWARD_SWEEP, 0, 0, 0, 0, mc->b_p, mc->y_p, stream));
+    PMG_CALL(mcsor_sweep_lrc(mc, PMG_SOR_BACKWARD_SWEEP, 0, 0, 0, 0, mc->b_p, mc->y_p, stream));
   } else {
-    PMG_CALL(mcsor_one_sweep(mc, mc->type, 0, 0, 0, 0, mc->b_p, mc->y_p, stream));
+    PMG_CALL(mcsor_sweep_lrc(mc, mc->type, 0, 0, 0, 0, mc->b_p, mc->y_p, stream));
   }
   PMG_KERNEL(pmgk_permute_out(mc->S.ld, mc->S.orig, mc->y_p, y, stream));
   return PMG_SUCCESS;
@@ -404,10 +416,10 @@ pmg_status pmg_mcsor_sample(pmg_mcsor mc, const double *b, double *y, int32_t it
   uint64_t ctr = counter0;
   for (int it = 0; it < its; ++it) {
     if (mc->type == PMG_SOR_SYMMETRIC_SWEEP) { /* src/pc_mcgibbs.c:172-181 */
-      PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_FORWARD_SWEEP, 1, scaled, seed, ctr++, mc->b_p, mc->y_p, stream));
-      PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_BACKWARD_SWEEP, 1, scaled, seed, ctr++, mc->b_p, mc->y_p, stream));
+      PMG_CALL(mcsor_sweep_lrc(mc, PMG_SOR_FORWARD_SWEEP, 1, scaled, seed, ctr++, mc->b_p, mc->y_p, stream));
+      PMG_CALL(mcsor_sweep_lrc(mc, PMG_SOR_BACKWARD_SWEEP, 1, scaled, seed, ctr++, mc->b_p, mc->y_p, stream));
     } else {
-      PMG_CALL(mcsor_one_sweep(mc, mc->type, 1, scaled, seed, ctr++, mc->b_p, mc->y_p, stream));
+      PMG_CALL(mcsor_sweep_lrc(mc, mc->type, 1, scaled, seed, ctr++, mc->b_p, mc->y_p, stream));
     }
   }
   PMG_KERNEL(pmgk_permute_out(mc->S.ld, mc->S.orig, mc->y_p, y, stream));
@@ -466,10 +478,10 @@ pmg_status pmg_mcsor_apply_layout(pmg_mcsor mc, const double *b_lay, double *y_l
   PMG_CHECK(mc && b_lay && y_lay, PMG_ERR_ARG_NULL, "null argument");
   PMG_CALL(mcsor_ready(mc));
   if (mc->type == PMG_SOR_SYMMETRIC_SWEEP) {
-    PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_FORWARD_SWEEP, 0, 0, 0, 0, b_lay, y_lay, stream));
-    PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_BACKWARD_SWEEP, 0, 0, 0, 0, b_lay, y_lay, stream));
+    PMG_CALL(mcsor_sweep_lrc(mc, PMG_SOR_FORWARD_SWEEP, 0, 0, 0, 0, b_lay, y_lay, stream));
+    PMG_CALL(mcsor_sweep_lrc(mc, PMG_SOR_BACKWARD_SWEEP, 0, 0, 0, 0, b_lay, y_lay, stream));
   } else {
-    PMG_CALL(mcsor_one_sweep(mc, mc->type, 0, 0, 0, 0, b_lay, y_lay, stream));
+    PMG_CALL(mcsor_sweep_lrc(mc, mc->type, 0, 0, 0, 0, b_lay, y_lay, stream));
   }
   return PMG_SUCCESS;
 }
@@ -483,10 +495,10 @@ pmg_status pmg_mcsor_sample_layout(pmg_mcsor mc, const double *b_lay, double *y_
   uint64_t ctr = counter0;
   for (int it = 0; it < its; ++it) {
     if (mc->type == PMG_SOR_SYMMETRIC_SWEEP) {
-      PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_FORWARD_SWEEP, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
-      PMG_CALL(mcsor_one_sweep(mc, PMG_SOR_BACKWARD_SWEEP, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
+      PMG_CALL(mcsor_sweep_lrc(mc, PMG_SOR_FORWARD_SWEEP, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
+      PMG_CALL(mcsor_sweep_lrc(mc, PMG_SOR_BACKWARD_SWEEP, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
     } else {
-      PMG_CALL(mcsor_one_sweep(mc, mc->type, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
+      PMG_CALL(mcsor_sweep_lrc(mc, mc->type, 1, scaled, seed, ctr++, b_lay, y_lay, stream));
     }
   }
   if (counter_out) *counter_out = ctr;
@@ -501,9 +513,32 @@ pmg_status pmg_mcsor_residual_layout(pmg_mcsor mc, const double *b_lay, const do
   return PMG_SUCCESS;
 }
 
+static pmg_status mcsor_det_sweep(void *ctx, int dir, const double *b_lay, double *y_lay, void *stream)
+{
+  return mcsor_one_sweep((pmg_mcsor)ctx, dir, 0, 0, 0, 0, b_lay, y_lay, stream);
+}
+
+/* MCSORSetUp's MATLRC branch (src/mc_sor.c:572-595): B is n x k column-major in the matrix's row numbering,
+   S the k diagonal entries of Sigma^-1.  k = 0 removes the update. */
+pmg_status pmg_mcsor_set_lowrank(pmg_mcsor mc, int32_t k, const double *B_host, const double *S_host)
+{
+  PMG_CHECK(mc, PMG_ERR_ARG_NULL, "null MCSOR");
+  PMG_CALL(mcsor_ready(mc));
+  pmg_lrc_destroy(&mc->lrc);
+  if (k == 0) return PMG_SUCCESS;
+  int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)(mc->n > 0 ? mc->n : 1));
+  PMG_CHECK(pos, PMG_ERR_MEM, "out of host memory");
+  for (int32_t p = 0; p < mc->S.ld; ++p)
+    if (mc->orig_host[p] >= 0) pos[mc->orig_host[p]] = p;
+  pmg_status st = pmg_lrc_build(&mc->lrc, k, mc->S.ld, mc->n, B_host, pos, S_host, mcsor_det_sweep, mc);
+  free(pos);
+  return st;
+}
+
 pmg_status pmg_mcsor_destroy(pmg_mcsor *mc)
 {
   if (!mc || !*mc) return PMG_SUCCESS;
+  pmg_lrc_destroy(&(*mc)->lrc);
   mcsor_free_setup(*mc);
   free((*mc)->user_colors);
   free(*mc);

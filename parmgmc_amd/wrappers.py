@@ -81,6 +81,12 @@ class MCSOR:
     def residual(self, b, y, r):
         check(lib.pmg_mcsor_residual(self._h, _ptr(b), _ptr(y), _ptr(r), _stream()))
 
+    def set_lowrank(self, B, S):
+        """MATLRC A + B diag(S) B^T: B (n x k), S (k) host arrays (reference src/mc_sor.c:572-595)."""
+        B = np.asfortranarray(B, dtype=np.float64)
+        S = np.ascontiguousarray(S, np.float64)
+        check(lib.pmg_mcsor_set_lowrank(self._h, B.shape[1], B.ctypes.data, S.ctypes.data))
+
     def destroy(self):
         if self._h:
             check(lib.pmg_mcsor_destroy(C.byref(self._h)))
@@ -171,6 +177,11 @@ class GridMCSOR:
         a, b, n = C.c_int64(), C.c_int64(), C.c_int64()
         check(lib.pmg_grid_halo_plane(self._h, color, side, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def set_lowrank(self, B, S):
+        B = np.asfortranarray(B, dtype=np.float64)
+        S = np.ascontiguousarray(S, np.float64)
+        check(lib.pmg_grid_set_lowrank(self._h, B.shape[1], B.ctypes.data, S.ctypes.data))
 
     def residual_cvec(self, b, y, r):
         check(lib.pmg_grid_residual_cvec(self._h, _ptr(b), _ptr(y), _ptr(r), _stream()))
