@@ -169,6 +169,26 @@ pmg_status pmg_grid_sample(pmg_grid g, const double *b_nat_dev, double *y_nat_de
 pmg_status pmg_grid_destroy(pmg_grid *g);
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* Multi-GPU sample loop on a z-slab decomposition: one process per GPU, per-colour halo exchange over RCCL     */
+/* (ncclSend/ncclRecv across xGMI) overlapped with the interior sweep.  Replaces MCSORApply_MPIAIJ's per-colour */
+/* VecScatter (src/mc_sor.c:317-340).                                                                           */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef struct pmg_dist_s *pmg_dist;
+/* rank 0: ncclGetUniqueId (128 bytes) to be broadcast to the other ranks by the launcher (torch.distributed / MPI).
+   rccl_path: shared object to dlopen (NULL = "librccl.so.1"); beside PyTorch pass torch's bundled librccl.so. */
+pmg_status pmg_dist_get_unique_id(const char *rccl_path, void *id128);
+/* `g` owns this rank's planes (pmg_grid_create with kz0/nz).  nranks == 1 needs no RCCL (id128 may be NULL) unless
+   loopback != 0, which makes the single rank its own z-neighbour for the HALO ONLY (exercises ncclSend/ncclRecv on
+   one GPU; the ghost planes are written but never read because both slab faces are physical boundaries). */
+pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void *id128, const char *rccl_path, int loopback, pmg_dist *d);
+/* `its` samples of the sorgibbs (scaled = 0) / mcgibbs (scaled = 1) chain on this rank's slab, cvec vectors,
+   sweep_type as PMG_SOR_*; noise counters counter0, counter0+1, ... exactly like pmg_grid_sample_cvec, so the
+   chain is bit-identical for every number of ranks.  Work is enqueued on `stream` and an internal comm stream;
+   `stream` is made to wait for the last exchange before the call returns. */
+pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b_cvec, double *y_cvec, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+pmg_status pmg_dist_destroy(pmg_dist *d);
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* Exact coarse sampler: replaces PCCHOLSAMPLER's dense path (src/pc_chols.c:174-194, :220-291)             */
 /* ------------------------------------------------------------------------------------------------------ */
 typedef struct pmg_chol_s *pmg_chol;

@@ -48,6 +48,16 @@ def _share_torch_hip_runtime() -> None:
         C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
 
 
+def torch_rccl_path() -> str | None:
+    """The librccl.so PyTorch bundles (so that a process beside torch keeps ONE RCCL), or None."""
+    try:
+        import torch
+    except Exception:
+        return None
+    cand = Path(torch.__file__).resolve().parent / "lib" / "librccl.so"
+    return str(cand) if cand.exists() else None
+
+
 def _load() -> C.CDLL:
     _share_torch_hip_runtime()
     p = library_path()
@@ -103,6 +113,10 @@ _sig = {
     "pmg_grid_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_grid_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_grid_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_dist_get_unique_id": (_int, [C.c_char_p, _vp]),
+    "pmg_dist_create": (_int, [_vp, _i32, _i32, _vp, C.c_char_p, _int, C.POINTER(_vp)]),
+    "pmg_dist_sample_cvec": (_int, [_vp, _vp, _vp, _i32, _int, _int, _u64, _u64, C.POINTER(_u64), _vp]),
+    "pmg_dist_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_chol_create_csr": (_int, [_i32, _vp, _vp, _vp, C.POINTER(_vp)]),
     "pmg_chol_get_factor": (_int, [_vp, _vp]),
     "pmg_chol_sample": (_int, [_vp, _vp, _vp, _int, _u64, _u64, _vp]),

@@ -103,10 +103,65 @@ def run_samples(sweep_planes, halo: SlabHalo, nz: int, b, y, its: int, sweep_typ
     return ctr
 
 
-class DistGridSampler:
-    """sorgibbs/mcgibbs sampler for the grid operator on `world` GPUs (this process = one slab)."""
+class RcclSlabDriver:
+    """The C sample loop of pmg_dist.c: RCCL send/recv called straight from the host library, comm stream + events,
+    no Python in the loop.  The 128-byte ncclUniqueId of rank 0 is broadcast through torch.distributed."""
 
-    def __init__(self, nx, ny, nz, kappa, rank, world, omega=1.0, sweep_type=SOR_FORWARD_SWEEP, scaled=True, group=None):
+    def __init__(self, grid, rank: int, world: int, loopback: bool = False, group=None):
+        import ctypes as C
+
+        from . import capi
+        from .capi import check, lib
+
+        self._h = C.c_void_p()
+        path = capi.torch_rccl_path()
+        pbytes = path.encode() if path else None
+        uid = None
+        if world > 1 or loopback:
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                check(lib.pmg_dist_get_unique_id(pbytes, buf))
+            payload = [bytes(buf.raw)]
+            if world > 1:
+                import torch.distributed as dist
+
+                dist.broadcast_object_list(payload, src=0, group=group)
+            uid = C.create_string_buffer(payload[0], 128)
+        check(lib.pmg_dist_create(grid._h, rank, world, uid, pbytes, int(loopback), C.byref(self._h)))
+        self._grid = grid  # keep alive
+
+    def sample_cvec(self, b, y, its, scaled, sweep_type, seed, counter0):
+        import ctypes as C
+
+        from .capi import check, lib
+        from .wrappers import _ptr, _stream
+
+        out = C.c_uint64()
+        check(lib.pmg_dist_sample_cvec(self._h, _ptr(b), _ptr(y), its, int(scaled), sweep_type, seed, counter0, C.byref(out), _stream()))
+        return out.value
+
+    def __del__(self):
+        try:
+            import ctypes as C
+
+            from .capi import lib
+
+            if self._h:
+                lib.pmg_dist_destroy(C.byref(self._h))
+        except Exception:
+            pass
+
+
+class DistGridSampler:
+    """sorgibbs/mcgibbs sampler for the grid operator on `world` GPUs (this process = one slab).
+
+    transport "rccl" (default when torch.distributed runs on the nccl backend): the C loop of pmg_dist.c;
+    transport "torch": the Python loop `run_samples` over torch.distributed P2P (gloo in the CPU tests; also the
+    automatic fall-back if RCCL cannot be initialised)."""
+
+    def __init__(self, nx, ny, nz, kappa, rank, world, omega=1.0, sweep_type=SOR_FORWARD_SWEEP, scaled=True, group=None, transport=None):
+        import os
+
         from .wrappers import GridMCSOR
 
         cuts = slab_cuts(nz, world)
@@ -116,10 +171,33 @@ class DistGridSampler:
         self.sweep_type, self.scaled = sweep_type, scaled
         planes = [[self.grid.halo_plane(c, s) for s in (0, 1)] for c in (0, 1)]
         self.halo = SlabHalo(rank, world, planes, group)
+        self.rccl = None
+        transport = transport or os.environ.get("PMG_DIST_TRANSPORT")
+        if world > 1 and transport != "torch":
+            import torch.distributed as dist
+
+            if transport == "rccl" or dist.get_backend(group) == "nccl":
+                ok = 1
+                try:
+                    self.rccl = RcclSlabDriver(self.grid, rank, world, group=group)
+                except Exception as e:  # fall back together: every rank must take the same path
+                    ok = 0
+                    err = e
+                import torch
+
+                flag = torch.tensor([ok], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if int(flag.item()) == 0:
+                    if rank == 0:
+                        print(f"[parmgmc_amd] RCCL transport unavailable ({err if not ok else 'on another rank'}); using torch.distributed P2P", flush=True)
+                    self.rccl = None
+        self.transport = "rccl" if self.rccl else ("torch" if world > 1 else "none")
 
     def sample_cvec(self, b, y, its: int, seed: int, counter0: int = 0) -> int:
         if self.world == 1:
             self.grid.set_sweep_type(self.sweep_type)
             return self.grid.sample_cvec(b, y, its, seed, counter0, self.scaled)
+        if self.rccl:
+            return self.rccl.sample_cvec(b, y, its, self.scaled, self.sweep_type, seed, counter0)
         g = self.grid
         return run_samples(lambda c, k0, nk, bb, yy, ctr: g.sweep_color_planes_cvec(c, k0, nk, bb, yy, True, self.scaled, seed, ctr), self.halo, g.nz, b, y, its, self.sweep_type, counter0)

@@ -72,3 +72,34 @@ def test_ranks_on_one_gpu_reproduce_the_single_device_chain(sweep_type, world):
     ctr = one.sample(torch.as_tensor(b_all, device="cuda"), yd, its, seed=42, counter0=1)
     assert np.array_equal(got, yd.cpu().numpy())  # bit-identical chain for any number of ranks
     assert all(x[2] == ctr for x in parts)
+
+
+def test_rccl_driver_loopback_on_one_gpu():
+    """The C/RCCL sample loop (pmg_dist.c) on ONE GPU: a single rank made its own z-neighbour for the halo.  This
+    exercises dlopen of RCCL, ncclCommInitRank, grouped ncclSend/ncclRecv on the comm stream and the event
+    choreography; both slab faces are physical boundaries, so the result must equal the plain sampler bit for bit,
+    and after the call each ghost plane must hold the matching boundary plane (the send really happened)."""
+    import torch
+
+    from parmgmc_amd import GridMCSOR
+    from parmgmc_amd.dist import RcclSlabDriver
+
+    nx, ny, nz, kappa = 36, 10, 7, 2.0
+    rng = np.random.default_rng(1)
+    b0, y0 = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
+    g = GridMCSOR(nx, ny, nz, kappa)
+    g.set_omega(1.2)
+    drv = RcclSlabDriver(g, 0, 1, loopback=True)
+    b, y = g.to_cvec(torch.as_tensor(b0, device="cuda")), g.to_cvec(torch.as_tensor(y0, device="cuda"))
+    ctr = drv.sample_cvec(b, y, 3, True, 3, 17, 5)  # symmetric sweeps
+    torch.cuda.synchronize()
+    ref = GridMCSOR(nx, ny, nz, kappa)
+    ref.set_omega(1.2)
+    ref.set_sweep_type(3)
+    yr = ref.to_cvec(torch.as_tensor(y0, device="cuda"))
+    assert ref.sample_cvec(b, yr, 3, 17, 5) == ctr == 11
+    assert np.array_equal(g.from_cvec(y).cpu().numpy(), ref.from_cvec(yr).cpu().numpy())
+    for c in (0, 1):
+        for side in (0, 1):
+            own, ghost, n = g.halo_plane(c, side)
+            assert torch.equal(y[ghost:ghost + n], y[own:own + n]) and float(y[own:own + n].abs().sum()) > 0
