@@ -44,8 +44,12 @@ __device__ __forceinline__ double uniform(double v)
 //     the set of open DRAM pages compact.
 // Boundary handling is branch-free: an absent neighbour is read from a clamped (valid, finite) address and
 // enters with coefficient 0 instead of h2, which adds an exact +0.
-template <bool NOISY, bool OMEGA1>
-__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+// HALO (multi-GPU face planes, transport "ipc"): the other colour's ghost plane below / above the slab is read from
+// `halo.glo` / `halo.ghi` (one plane each, this rank's receive block) instead of the vector's own ghost planes, and
+// the results of plane 0 / nz-1 are ALSO stored into `halo.plo` / `halo.phi`, which point into the z-neighbours'
+// receive blocks (peer memory over xGMI): the halo exchange costs no extra launch and no copy.
+template <bool NOISY, bool OMEGA1, bool HALO>
+__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
 {
   // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
   // wave-uniform; readfirstlane tells the compiler, which then keeps the boundary logic on the scalar unit
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
   // is the XCD], or (nbx, nby, nz) in plain order
   const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
-  const int k  = kbegin + (int)blockIdx.z;
+  const int k  = kbegin + (int)blockIdx.z * kstride;
   const int t = bx * 64 + threadIdx.x;
   const int j = by * 4 + ty;
   if (j >= L.ny || 2 * t >= L.sx) return;
@@ -79,8 +83,9 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
   const double ed = yo[eo];
   const d2     oS = ld2(yo - (hasS ? L.sx : 0));
   const d2     oN = ld2(yo + (hasN ? L.sx : 0));
-  const d2     oD = ld2(yo - (hasD ? L.sp : 0));
-  const d2     oU = ld2(yo + (hasU ? L.sp : 0));
+  const int64_t inplane = (int64_t)j * L.sx + 2 * t; // offset inside one plane
+  const d2      oD = (HALO && k == 0 && halo.glo) ? ld2(halo.glo + inplane) : ld2(yo - (hasD ? L.sp : 0));
+  const d2      oU = (HALO && k == L.nz - 1 && halo.ghi) ? ld2(halo.ghi + inplane) : ld2(yo + (hasU ? L.sp : 0));
   const d2     bb = ld2(b_own + line);
 
   const double L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
@@ -130,6 +135,10 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
   // the slot of a non-existent second point (odd nx) is a pad slot of this line: keep it zero
   const d2 out = {r0, v1 ? r1 : 0.0};
   *reinterpret_cast<d2 *>(y_own + line) = out;
+  if (HALO) {
+    if (k == 0 && halo.plo) *reinterpret_cast<d2 *>(halo.plo + inplane) = out;
+    if (k == L.nz - 1 && halo.phi) *reinterpret_cast<d2 *>(halo.phi + inplane) = out;
+  }
 }
 
 // --- first version kept for A/B timing (PMG_GRID_VARIANT=0) ---
@@ -296,7 +305,7 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
 
-extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, const double *b, double *y, void *stream)
+extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, int kstride, const pmgk_grid_halo *halo, const double *b, double *y, void *stream)
 {
   if (kcount <= 0) return 0;
   const int tpl = L->sx / 2; // threads per line
@@ -307,7 +316,7 @@ extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_
   }
   if (variant == 0) {
     const dim3 block(64, 4, 1);
-    if (kbegin != 0 || kcount != L->nz) return 2; /* the A/B variant sweeps whole slabs only */
+    if (kbegin != 0 || kcount != L->nz || kstride != 1 || halo) return 2; /* the A/B variant sweeps whole slabs only */
     const dim3 grid((tpl + 63) / 64, (L->ny + 3) / 4, L->nz);
     hipStream_t s = (hipStream_t)stream;
     if (op->noisy) {
@@ -332,12 +341,22 @@ extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_
   hipStream_t   s  = (hipStream_t)stream;
   const double *bo = b + (int64_t)color * L->cs, *yo = y + (int64_t)(1 - color) * L->cs;
   double       *ys = y + (int64_t)color * L->cs;
-  if (op->noisy) {
-    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, bo, yo, ys);
-    else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, bo, yo, ys);
+  pmgk_grid_halo h0 = {nullptr, nullptr, nullptr, nullptr};
+  if (halo) {
+    const pmgk_grid_halo h = *halo;
+    if (op->noisy) {
+      if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+      else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+    } else {
+      if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+      else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+    }
+  } else if (op->noisy) {
+    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
+    else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
   } else {
-    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, bo, yo, ys);
-    else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, bo, yo, ys);
+    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
+    else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
   }
   return launch_status();
 }

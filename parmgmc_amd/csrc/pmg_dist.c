@@ -13,12 +13,24 @@
  * is what makes re-use of the send and ghost planes safe without further flags.  Noise depends on global indices
  * only: the chain is bit-identical for every number of devices.
  *
+ * Second transport, "ipc" (same schedule, for the latency-bound strong-scaling regime where a 1 MB RCCL send/recv
+ * kernel costs ~40 us): every rank owns a small receive block (one plane per colour and side) exported with
+ * hipIpcGetMemHandle; a push is a plain device-to-device copy of the boundary plane INTO the neighbour's block over
+ * xGMI, followed by an interprocess event; the receiver waits on that event in its compute stream and copies the
+ * plane into its ghost plane.  hipStreamWaitEvent binds to the most recent record at call time, so a host-side
+ * sequence number in POSIX shared memory tells the receiver that the sender has ISSUED the record of the round it
+ * needs (hosts run in lockstep anyway; no GPU ever spins).
+ *
  * RCCL is loaded at run time (dlopen of the path the caller names -- the copy PyTorch bundles when used beside
  * torch, so that the process keeps one RCCL and one HIP runtime); no link-time dependency.
  */
 #define _GNU_SOURCE
 #include "pmg_internal.h"
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <stdatomic.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 typedef struct {
   char internal[128];
@@ -66,7 +78,29 @@ static pmg_status rccl_load(const char *path, pmg_rccl_api *api)
     if (pmg_r_ != 0) return pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "%s: %s", #expr, (d)->api.GetErrorString(pmg_r_)); \
   } while (0)
 
+#define PMG_IPC_MAXRANKS 64
+typedef struct {
+  _Atomic uint64_t seq[PMG_IPC_MAXRANKS][2]; /* pushes of colour c issued by rank r */
+} pmg_ipc_shm;
+
+typedef struct {
+  hipIpcMemHandle_t   mem;   /* the rank's receive block: recv[colour][side], `plane` doubles each */
+  hipIpcEventHandle_t ev[2]; /* "my push of colour c has landed" */
+  int64_t             plane; /* doubles per plane (must agree between neighbours) */
+} pmg_ipc_blob;
+
 struct pmg_dist_s {
+  int           transport; /* 0 = RCCL, 1 = IPC peer copies */
+  /* ipc */
+  double       *recv;            /* own receive block (4 planes) */
+  double       *peer_recv[2];    /* neighbours' receive blocks, mapped (side 0 = lo, 1 = hi) */
+  hipEvent_t    ipc_ev[2];       /* own interprocess events */
+  hipEvent_t    peer_ev[2][2];   /* [side][colour] neighbours' events */
+  hipEvent_t    evP[2];          /* local: push of colour c has read my boundary planes */
+  pmg_ipc_shm  *shm;
+  char          shm_name[64];
+  uint64_t      round[2];        /* pushes of colour c issued so far */
+  int64_t       plane;
   pmg_grid      g;
   int           rank, nranks, lo, hi; /* z-neighbours (-1 = physical boundary); lo == hi == rank in loopback mode */
   int           loopback;
@@ -134,10 +168,214 @@ pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void 
   return PMG_SUCCESS;
 }
 
+/* ---- IPC transport --------------------------------------------------------------------------------------- */
+
+pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, const void *token16, pmg_dist *out)
+{
+  PMG_CHECK(out && g && token16, PMG_ERR_ARG_NULL, "null argument");
+  *out = NULL;
+  PMG_CHECK(nranks >= 1 && nranks <= PMG_IPC_MAXRANKS && rank >= 0 && rank < nranks, PMG_ERR_ARG_OUTOFRANGE, "rank %d of %d", rank, nranks);
+  pmg_dist d = (pmg_dist)calloc(1, sizeof *d);
+  PMG_CHECK(d, PMG_ERR_MEM, "out of host memory");
+  d->transport = 1;
+  d->g         = g;
+  d->rank      = rank;
+  d->nranks    = nranks;
+  d->lo        = rank > 0 ? rank - 1 : -1;
+  d->hi        = rank < nranks - 1 ? rank + 1 : -1;
+  pmgk_grid_layout L;
+  pmg_status       st = pmg_grid_get_kernel_layout(g, &L);
+  d->nz               = L.nz;
+  d->plane            = L.sp;
+  if (!st && hipMalloc((void **)&d->recv, sizeof(double) * 4 * (size_t)d->plane) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipMalloc of the halo receive block failed");
+  if (!st && hipMemset(d->recv, 0, sizeof(double) * 4 * (size_t)d->plane) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+  if (!st && hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "stream creation failed");
+  for (int c = 0; c < 2 && !st; ++c) {
+    if (hipEventCreateWithFlags(&d->evB[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evP[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ipc_ev[c], hipEventDisableTiming | hipEventInterprocess) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+  }
+  if (!st && hipEventCreateWithFlags(&d->evS, hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+  if (!st) { /* host-side sequence numbers in POSIX shared memory, named after the job token */
+    const unsigned char *t = (const unsigned char *)token16;
+    snprintf(d->shm_name, sizeof d->shm_name, "/pmg_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]);
+    const int fd = shm_open(d->shm_name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)sizeof(pmg_ipc_shm)) != 0) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "shm_open(%s) failed", d->shm_name);
+    if (!st) {
+      void *m = mmap(NULL, sizeof(pmg_ipc_shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      if (m == MAP_FAILED) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "mmap of %s failed", d->shm_name);
+      else d->shm = (pmg_ipc_shm *)m;
+    }
+    if (fd >= 0) close(fd);
+  }
+  if (st) {
+    pmg_dist_destroy(&d);
+    return st;
+  }
+  *out = d;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_dist_ipc_blob_bytes(int32_t *bytes)
+{
+  PMG_CHECK(bytes, PMG_ERR_ARG_NULL, "null argument");
+  *bytes = (int32_t)sizeof(pmg_ipc_blob);
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_dist_ipc_export(pmg_dist d, void *blob)
+{
+  PMG_CHECK(d && blob && d->transport == 1, PMG_ERR_ARG_WRONG, "not an IPC dist object");
+  pmg_ipc_blob bl;
+  memset(&bl, 0, sizeof bl);
+  PMG_HIP(hipIpcGetMemHandle(&bl.mem, d->recv));
+  for (int c = 0; c < 2; ++c) PMG_HIP(hipIpcGetEventHandle(&bl.ev[c], d->ipc_ev[c]));
+  bl.plane = d->plane;
+  memcpy(blob, &bl, sizeof bl);
+  return PMG_SUCCESS;
+}
+
+/* blobs of the z-neighbours (NULL where there is none); all ranks must have exported before anyone connects */
+pmg_status pmg_dist_ipc_connect(pmg_dist d, const void *blob_lo, const void *blob_hi)
+{
+  PMG_CHECK(d && d->transport == 1, PMG_ERR_ARG_WRONG, "not an IPC dist object");
+  const void *blobs[2] = {blob_lo, blob_hi};
+  const int   nb[2]    = {d->lo, d->hi};
+  for (int side = 0; side < 2; ++side) {
+    if (nb[side] < 0) continue;
+    PMG_CHECK(blobs[side], PMG_ERR_ARG_NULL, "missing blob of neighbour rank %d", nb[side]);
+    pmg_ipc_blob bl;
+    memcpy(&bl, blobs[side], sizeof bl);
+    PMG_CHECK(bl.plane == d->plane, PMG_ERR_ARG_SIZ, "neighbour plane size %lld != %lld", (long long)bl.plane, (long long)d->plane);
+    PMG_HIP(hipIpcOpenMemHandle((void **)&d->peer_recv[side], bl.mem, hipIpcMemLazyEnablePeerAccess));
+    for (int c = 0; c < 2; ++c) PMG_HIP(hipIpcOpenEventHandle(&d->peer_ev[side][c], bl.ev[c]));
+  }
+  return PMG_SUCCESS;
+}
+
+/* single rank as its own z-neighbour for the halo only (timing / smoke test on one GPU, like the RCCL loopback):
+   the "peer" receive block and events are the rank's own, no IPC handle is opened */
+pmg_status pmg_dist_ipc_connect_loopback(pmg_dist d)
+{
+  PMG_CHECK(d && d->transport == 1 && d->nranks == 1, PMG_ERR_ARG_WRONG, "loopback needs a single-rank IPC dist object");
+  d->lo = d->hi = 0;
+  d->loopback   = 1;
+  for (int side = 0; side < 2; ++side) {
+    d->peer_recv[side] = d->recv;
+    for (int c = 0; c < 2; ++c) d->peer_ev[side][c] = d->evP[c]; /* recorded at the same point as the interprocess event */
+  }
+  return PMG_SUCCESS;
+}
+
+/* rank 0, after every rank has mapped it: remove the name of the shared-memory object */
+pmg_status pmg_dist_ipc_unlink(pmg_dist d)
+{
+  PMG_CHECK(d && d->transport == 1, PMG_ERR_ARG_WRONG, "not an IPC dist object");
+  if (d->shm_name[0]) shm_unlink(d->shm_name);
+  return PMG_SUCCESS;
+}
+
+/* Initial push (start of a call): copy my boundary planes of colour c into the neighbours' receive blocks on the comm
+   stream.  Later pushes are done by the face kernel itself (HALO mode), see ipc_sample. */
+static pmg_status ipc_push_copy(pmg_dist d, int c, const double *y, hipEvent_t after)
+{
+  PMG_HIP(hipStreamWaitEvent(d->cs, after, 0));
+  int64_t own, ghost, n;
+  for (int side = 0; side < 2; ++side) {
+    if ((side == 0 ? d->lo : d->hi) < 0) continue;
+    PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
+    /* my low plane lands in the neighbour's HIGH slot and vice versa: recv[(c*2 + their_side) * plane] */
+    double *dst = d->peer_recv[side] + (int64_t)(c * 2 + (1 - side)) * d->plane;
+    PMG_HIP(hipMemcpyAsync(dst, y + own, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, d->cs));
+  }
+  PMG_HIP(hipEventRecord(d->ipc_ev[c], d->cs)); /* neighbours wait on this */
+  PMG_HIP(hipEventRecord(d->evP[c], d->cs));    /* local twin: I wait on it before rewriting the planes */
+  d->round[c] += 1;
+  atomic_store_explicit(&d->shm->seq[d->rank][c], d->round[c], memory_order_release);
+  return PMG_SUCCESS;
+}
+
+/* make stream s wait until both neighbours' pushes number round[c] of colour c have landed in my receive block */
+static pmg_status ipc_wait(pmg_dist d, int c, hipStream_t s)
+{
+  for (int side = 0; side < 2; ++side) {
+    const int nb = side == 0 ? d->lo : d->hi;
+    if (nb < 0) continue;
+    uint64_t spins = 0;
+    while (atomic_load_explicit(&d->shm->seq[nb][c], memory_order_acquire) < d->round[c]) { /* the record has been ISSUED */
+      if (++spins > 4000000000ull) PMG_FAIL(PMG_ERR_LIB, "rank %d: neighbour %d never issued push %llu of colour %d", d->rank, nb, (unsigned long long)d->round[c], c);
+    }
+    PMG_HIP(hipStreamWaitEvent(s, d->peer_ev[side][c], 0));
+  }
+  return PMG_SUCCESS;
+}
+
+static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, hipStream_t s)
+{
+  const int32_t nz = d->nz;
+  PMG_HIP(hipEventRecord(d->evS, s));
+  PMG_CALL(ipc_push_copy(d, 0, y, d->evS)); /* the receive blocks hold nothing of this y yet */
+  PMG_CALL(ipc_push_copy(d, 1, y, d->evS));
+  uint64_t ctr = counter0;
+  for (int32_t it = 0; it < its; ++it) {
+    const int ndir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
+    for (int q = 0; q < ndir; ++q) {
+      const int dir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? (q == 0 ? PMG_SOR_FORWARD_SWEEP : PMG_SOR_BACKWARD_SWEEP) : sweep_type;
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = dir == PMG_SOR_FORWARD_SWEEP ? cc : 1 - cc;
+        PMG_CALL(ipc_wait(d, 1 - c, s));              /* colour c reads colour 1-c across the slab faces */
+        PMG_HIP(hipStreamWaitEvent(s, d->evP[c], 0)); /* (first sweep) the initial copy has read the planes I am about to rewrite */
+        /* face planes: read the neighbours' colour 1-c planes from my receive block, write the new colour-c planes
+           into y AND straight into the neighbours' receive blocks (peer stores over xGMI) */
+        pmgk_grid_halo h;
+        h.glo = d->lo >= 0 ? d->recv + (int64_t)((1 - c) * 2 + 0) * d->plane : NULL;
+        h.ghi = d->hi >= 0 ? d->recv + (int64_t)((1 - c) * 2 + 1) * d->plane : NULL;
+        h.plo = d->lo >= 0 ? d->peer_recv[0] + (int64_t)(c * 2 + 1) * d->plane : NULL;
+        h.phi = d->hi >= 0 ? d->peer_recv[1] + (int64_t)(c * 2 + 0) * d->plane : NULL;
+        PMG_CALL(pmg_grid_sweep_color_faces_cvec(d->g, c, 1, scaled, seed, ctr, &h, b, y, s));
+        /* "my push of colour c has landed" = completion of the face kernel.  Recording an INTERPROCESS event costs a
+           stream-write packet and a ~30 us bubble on the stream it is recorded on (measured), so it goes to the comm
+           stream behind a cheap local event and the compute stream runs straight on into the interior planes. */
+        PMG_HIP(hipEventRecord(d->evP[c], s));
+        PMG_HIP(hipStreamWaitEvent(d->cs, d->evP[c], 0));
+        PMG_HIP(hipEventRecord(d->ipc_ev[c], d->cs));
+        d->round[c] += 1;
+        atomic_store_explicit(&d->shm->seq[d->rank][c], d->round[c], memory_order_release);
+        if (nz > 2) PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, 1, nz - 2, 1, scaled, seed, ctr, b, y, s));
+      }
+      ++ctr;
+    }
+  }
+  /* leave y self-contained: bring the latest neighbour planes into its own ghost planes */
+  for (int c = 0; c < 2; ++c) {
+    PMG_CALL(ipc_wait(d, c, s));
+    int64_t own, ghost, n;
+    for (int side = 0; side < 2; ++side) {
+      if ((side == 0 ? d->lo : d->hi) < 0) continue;
+      PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
+      PMG_HIP(hipMemcpyAsync(y + ghost, d->recv + (int64_t)(c * 2 + side) * d->plane, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  if (counter_out) *counter_out = ctr;
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_dist_destroy(pmg_dist *dp)
 {
   if (!dp || !*dp) return PMG_SUCCESS;
   pmg_dist d = *dp;
+  if (d->transport == 1) {
+    (void)hipDeviceSynchronize();
+    for (int side = 0; side < 2 && !d->loopback; ++side) {
+      if (d->peer_recv[side]) (void)hipIpcCloseMemHandle(d->peer_recv[side]);
+      for (int c = 0; c < 2; ++c)
+        if (d->peer_ev[side][c]) (void)hipEventDestroy(d->peer_ev[side][c]);
+    }
+    for (int c = 0; c < 2; ++c) {
+      if (d->ipc_ev[c]) (void)hipEventDestroy(d->ipc_ev[c]);
+      if (d->evP[c]) (void)hipEventDestroy(d->evP[c]);
+    }
+    if (d->recv) (void)hipFree(d->recv);
+    if (d->shm) munmap(d->shm, sizeof(pmg_ipc_shm));
+  }
   if (d->comm && d->api.CommDestroy) d->api.CommDestroy(d->comm);
   for (int c = 0; c < 2; ++c) {
     if (d->evB[c]) (void)hipEventDestroy(d->evB[c]);
@@ -181,6 +419,7 @@ pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b, double *y, int32_t 
   PMG_CHECK(pmg_sweep_type_ok(sweep_type), PMG_ERR_SUP, "Only forward, backward and symmetric sweep supported");
   hipStream_t   s  = (hipStream_t)stream;
   const int32_t nz = d->nz;
+  if (d->transport == 1) return ipc_sample(d, b, y, its, scaled, sweep_type, seed, counter0, counter_out, s);
   /* the caller's y has no ghost values yet: exchange both colours once the caller's prior work is done */
   PMG_HIP(hipEventRecord(d->evS, s));
   PMG_CALL(dist_exchange(d, 0, y, d->evS));
@@ -193,8 +432,7 @@ pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b, double *y, int32_t 
       for (int cc = 0; cc < 2; ++cc) {
         const int c = dir == PMG_SOR_FORWARD_SWEEP ? cc : 1 - cc;
         PMG_HIP(hipStreamWaitEvent(s, d->evX[1 - c], 0)); /* colour c reads colour 1-c across the slab faces */
-        PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, 0, 1, 1, scaled, seed, ctr, b, y, s));
-        if (nz > 1) PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, nz - 1, 1, 1, scaled, seed, ctr, b, y, s));
+        PMG_CALL(pmg_grid_sweep_color_faces_cvec(d->g, c, 1, scaled, seed, ctr, NULL, b, y, s)); /* planes 0 and nz-1, one launch */
         PMG_HIP(hipEventRecord(d->evB[c], s));
         PMG_CALL(dist_exchange(d, c, y, d->evB[c]));
         if (nz > 2) PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, 1, nz - 2, 1, scaled, seed, ctr, b, y, s));

@@ -178,8 +178,8 @@ static pmg_status pmg_grid_one_sweep(pmg_grid g, int dir, int noisy, int scaled,
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, noisy, scaled, seed, sweep);
   const int c0 = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, b, y, stream));
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, 1, NULL, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, 1, NULL, b, y, stream));
   if (g->lrc) PMG_CALL(pmg_lrc_post(g->lrc, dir, y, stream));
   return PMG_SUCCESS;
 }
@@ -190,8 +190,8 @@ static pmg_status grid_det_sweep(void *ctx, int dir, const double *b, double *y,
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, 0, 0, 0, 0);
   const int c0 = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, b, y, stream));
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, 1, NULL, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, 1, NULL, b, y, stream));
   return PMG_SUCCESS;
 }
 
@@ -220,7 +220,7 @@ pmg_status pmg_grid_sweep_color_cvec(pmg_grid g, int color, int noisy, int scale
   PMG_CHECK(!noisy || scaled || g->omega == 1.0, PMG_ERR_SUP, "the unscaled (sorgibbs) noise requires omega = 1 (src/pc_sorgibbs.c:94)");
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, noisy != 0, scaled, seed, counter);
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, 0, g->L.nz, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, 0, g->L.nz, 1, NULL, b, y, stream));
   return PMG_SUCCESS;
 }
 
@@ -232,7 +232,20 @@ pmg_status pmg_grid_sweep_color_planes_cvec(pmg_grid g, int color, int32_t kbegi
   PMG_CHECK(!noisy || scaled || g->omega == 1.0, PMG_ERR_SUP, "the unscaled (sorgibbs) noise requires omega = 1 (src/pc_sorgibbs.c:94)");
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, noisy != 0, scaled, seed, counter);
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, kbegin, kcount, b, y, stream));
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, kbegin, kcount, 1, NULL, b, y, stream));
+  return PMG_SUCCESS;
+}
+
+/* both slab faces (planes 0 and nz-1) of one colour in ONE launch: the part of a colour pass that reads ghost planes */
+pmg_status pmg_grid_sweep_color_faces_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const pmgk_grid_halo *halo, const double *b, double *y, void *stream)
+{
+  PMG_CHECK(g && b && y, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(color == 0 || color == 1, PMG_ERR_ARG_OUTOFRANGE, "colour %d", color);
+  PMG_CHECK(!noisy || scaled || g->omega == 1.0, PMG_ERR_SUP, "the unscaled (sorgibbs) noise requires omega = 1 (src/pc_sorgibbs.c:94)");
+  pmgk_grid_op op;
+  pmg_grid_fill_op(g, &op, noisy != 0, scaled, seed, counter);
+  const int nz = g->L.nz;
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, 0, nz > 1 ? 2 : 1, nz > 1 ? nz - 1 : 1, halo, b, y, stream));
   return PMG_SUCCESS;
 }
 

@@ -41,8 +41,14 @@ typedef struct {
   int32_t  omega_is_one;
 } pmgk_grid_op;
 
-/* sweeps the colour-`color` points of owned planes [kbegin, kbegin+kcount) */
-int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, const double *b_cvec, double *y_cvec, void *stream);
+/* multi-GPU face planes: ghost planes of the OTHER colour to read (this rank's receive block) and destinations in
+   the z-neighbours' receive blocks (peer memory) for the freshly swept planes 0 / nz-1; null = unused */
+typedef struct {
+  const double *glo, *ghi;
+  double       *plo, *phi;
+} pmgk_grid_halo;
+/* sweeps the colour-`color` points of the kcount owned planes kbegin, kbegin+kstride, ...; halo may be NULL */
+int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, int kstride, const pmgk_grid_halo *halo, const double *b_cvec, double *y_cvec, void *stream);
 int pmgk_grid_to_cvec(const pmgk_grid_layout *L, const double *nat, double *cvec, void *stream);
 int pmgk_grid_from_cvec(const pmgk_grid_layout *L, const double *cvec, double *nat, void *stream);
 /* r = b - A y on cvecs (PCMGResidualDefault / src/pc_gamgmc.c:253-254) */

@@ -152,6 +152,43 @@ class RcclSlabDriver:
             pass
 
 
+class IpcSlabDriver(RcclSlabDriver):
+    """The C sample loop of pmg_dist.c with the "ipc" transport: boundary planes are copied device-to-device straight
+    into the neighbour's receive block (hipIpc memory, interprocess events); torch.distributed only carries the
+    bootstrap (16-byte job token, all-gather of the handle blobs, one barrier)."""
+
+    def __init__(self, grid, rank: int, world: int, group=None, loopback: bool = False):
+        import ctypes as C
+        import os
+
+        from .capi import check, lib
+
+        self._h = C.c_void_p()
+        self._grid = grid
+        if loopback:
+            check(lib.pmg_dist_create_ipc(grid._h, 0, 1, C.create_string_buffer(os.urandom(16), 16), C.byref(self._h)))
+            check(lib.pmg_dist_ipc_connect_loopback(self._h))
+            check(lib.pmg_dist_ipc_unlink(self._h))
+            return
+        import torch.distributed as dist
+
+        tok = [os.urandom(16)]
+        dist.broadcast_object_list(tok, src=0, group=group)
+        check(lib.pmg_dist_create_ipc(grid._h, rank, world, C.create_string_buffer(tok[0], 16), C.byref(self._h)))
+        nb = C.c_int32()
+        check(lib.pmg_dist_ipc_blob_bytes(C.byref(nb)))
+        blob = C.create_string_buffer(nb.value)
+        check(lib.pmg_dist_ipc_export(self._h, blob))
+        blobs = [None] * world
+        dist.all_gather_object(blobs, bytes(blob.raw), group=group)
+        lo = C.create_string_buffer(blobs[rank - 1], nb.value) if rank > 0 else None
+        hi = C.create_string_buffer(blobs[rank + 1], nb.value) if rank < world - 1 else None
+        check(lib.pmg_dist_ipc_connect(self._h, lo, hi))
+        dist.barrier(group=group)
+        if rank == 0:
+            check(lib.pmg_dist_ipc_unlink(self._h))
+
+
 class DistGridSampler:
     """sorgibbs/mcgibbs sampler for the grid operator on `world` GPUs (this process = one slab).
 
@@ -172,26 +209,29 @@ class DistGridSampler:
         planes = [[self.grid.halo_plane(c, s) for s in (0, 1)] for c in (0, 1)]
         self.halo = SlabHalo(rank, world, planes, group)
         self.rccl = None
-        transport = transport or os.environ.get("PMG_DIST_TRANSPORT")
-        if world > 1 and transport != "torch":
+        self.transport = "none" if world == 1 else "torch"
+        want = transport or os.environ.get("PMG_DIST_TRANSPORT")
+        if world > 1 and want != "torch":
+            import torch
             import torch.distributed as dist
 
-            if transport == "rccl" or dist.get_backend(group) == "nccl":
-                ok = 1
+            on_gpu = dist.get_backend(group) == "nccl"
+            # preference: ipc (peer copies, lowest latency) -> rccl (ncclSend/ncclRecv) -> torch P2P; every rank must
+            # take the same path, so success is agreed with an all-reduce after each attempt
+            candidates = [want] if want else (["ipc", "rccl"] if on_gpu else [])
+            for cand in candidates:
+                ok, err = 1, None
                 try:
-                    self.rccl = RcclSlabDriver(self.grid, rank, world, group=group)
-                except Exception as e:  # fall back together: every rank must take the same path
-                    ok = 0
-                    err = e
-                import torch
-
-                flag = torch.tensor([ok], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+                    drv = IpcSlabDriver(self.grid, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(self.grid, rank, world, group=group)
+                except Exception as e:
+                    ok, err, drv = 0, e, None
+                flag = torch.tensor([ok], device="cuda" if on_gpu else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                if int(flag.item()) == 0:
-                    if rank == 0:
-                        print(f"[parmgmc_amd] RCCL transport unavailable ({err if not ok else 'on another rank'}); using torch.distributed P2P", flush=True)
-                    self.rccl = None
-        self.transport = "rccl" if self.rccl else ("torch" if world > 1 else "none")
+                if int(flag.item()) == 1:
+                    self.rccl, self.transport = drv, cand
+                    break
+                if rank == 0:
+                    print(f"[parmgmc_amd] halo transport '{cand}' unavailable ({err if err else 'on another rank'}); trying the next one", flush=True)
 
     def sample_cvec(self, b, y, its: int, seed: int, counter0: int = 0) -> int:
         if self.world == 1:

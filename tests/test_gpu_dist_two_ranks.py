@@ -1,8 +1,10 @@
 """Two ranks sharing the ONE GPU of the test box: the production multi-device driver (`DistGridSampler`:
 slab ownership, boundary-first overlap schedule, HIP plane-range kernels, halo exchange through
 torch.distributed) against the single-device chain.  RCCL cannot run two ranks on one device, so the exchange
-goes through the `gloo` backend (staged through host memory by SlabHalo when the tensors are on the GPU); the
-kernels and the schedule are exactly the ones `bench.py --gpus N` runs with backend nccl."""
+goes either through the `gloo` backend (torch transport, staged through host memory by SlabHalo) or through the
+"ipc" transport of pmg_dist.c (hipIpc peer copies + interprocess events -- the SAME code path the multi-GPU run
+uses, only the peer happens to be the same device); the kernels and the schedule are the ones `bench.py --gpus N`
+runs."""
 import os
 import socket
 
@@ -20,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nx, ny, nz, kappa, omega, sweep_type, its, q):
+def _worker(rank, world, port, nx, ny, nz, kappa, omega, sweep_type, its, q, transport=None):
     import torch
     import torch.distributed as dist
 
@@ -30,22 +32,24 @@ def _worker(rank, world, port, nx, ny, nz, kappa, omega, sweep_type, its, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from parmgmc_amd.dist import DistGridSampler
 
-    smp = DistGridSampler(nx, ny, nz, kappa, rank, world, omega=omega, sweep_type=sweep_type)
+    smp = DistGridSampler(nx, ny, nz, kappa, rank, world, omega=omega, sweep_type=sweep_type, transport=transport)
+    assert smp.transport == (transport or "torch")
     g = smp.grid
     rng = np.random.default_rng(5)
     b_all, y_all = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
     lo, hi = g.kz0 * nx * ny, (g.kz0 + g.nz) * nx * ny
     b = g.to_cvec(torch.as_tensor(b_all[lo:hi], device="cuda"))
     y = g.to_cvec(torch.as_tensor(y_all[lo:hi], device="cuda"))
-    ctr = smp.sample_cvec(b, y, its, seed=42, counter0=1)
+    ctr = smp.sample_cvec(b, y, its - 1, seed=42, counter0=1)
+    ctr = smp.sample_cvec(b, y, 1, seed=42, counter0=ctr)  # a second call continues the chain
     torch.cuda.synchronize()
     q.put((rank, g.from_cvec(y).cpu().numpy(), ctr))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sweep_type,world", [(1, 2), (3, 3)])
-def test_ranks_on_one_gpu_reproduce_the_single_device_chain(sweep_type, world):
+@pytest.mark.parametrize("sweep_type,world,transport", [(1, 2, None), (3, 3, None), (1, 2, "ipc"), (3, 3, "ipc"), (2, 4, "ipc")])
+def test_ranks_on_one_gpu_reproduce_the_single_device_chain(sweep_type, world, transport):
     import torch
     import torch.multiprocessing as mp
 
@@ -55,7 +59,7 @@ def test_ranks_on_one_gpu_reproduce_the_single_device_chain(sweep_type, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, ny, nz, kappa, omega, sweep_type, its, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, ny, nz, kappa, omega, sweep_type, its, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     parts = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
