@@ -7,7 +7,8 @@ A "step" is ONE SAMPLE = one forward Gibbs sweep (= both colour passes, noise ge
 sorgibbs/mcgibbs sampler on the 7-point operator of MatAssembleShiftedLaplaceFD (reference src/problems.c:14-75,
 3-D analogue), kappa = 10, b = 1, x0 = 0, omega = 1 (reference examples/ex1.c:88,109), vectors resident in HBM
 in the library's colour-partitioned layout.  N ranks split the SAME 512^3 grid into z-slabs ("strong" scaling)
-and exchange one halo plane per colour per neighbour over RCCL.
+and exchange one halo plane per colour per neighbour over xGMI (transport "ipc": peer stores + interprocess events;
+fall-backs: RCCL ncclSend/ncclRecv from C, then torch.distributed P2P; PMG_DIST_TRANSPORT=ipc|rccl|torch forces one).
 
 The JSON line also carries
   roofline     -- dominant kernel (grid_color_sweep_kernel, one colour pass): algorithmic bytes per launch
@@ -27,6 +28,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: needed by RCCL and by the hipIpc halo transport
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -156,7 +158,7 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{n}^3 DMDA, 7-point shifted Laplacian (kappa=10, h2=1/(n-1)^2), b=1, x0=0, omega={args.omega:g}, forward red-black Gibbs sweep with in-kernel Philox4x32-10 + Box-Muller noise", "unknowns": N_total, "decomposition": f"{world} z-slab(s)", "halo": "none" if world == 1 else "1 plane/colour/neighbour over RCCL send/recv"},
+            "config": {"workload": f"{n}^3 DMDA, 7-point shifted Laplacian (kappa=10, h2=1/(n-1)^2), b=1, x0=0, omega={args.omega:g}, forward red-black Gibbs sweep with in-kernel Philox4x32-10 + Box-Muller noise", "unknowns": N_total, "decomposition": f"{world} z-slab(s)", "halo": "none" if world == 1 else {"ipc": "1 plane/colour/neighbour, stored by the face kernel straight into the neighbour's receive block over xGMI (hipIpc peer memory + interprocess events)", "rccl": "1 plane/colour/neighbour over RCCL ncclSend/ncclRecv", "torch": "1 plane/colour/neighbour over torch.distributed P2P (RCCL)"}[smp.transport], "transport": smp.transport},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None, "kernel": "grid_color_sweep_kernel", "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_us": t_launch * 1e6, "note": "24 B/unknown/sweep (read y, write y, read b once; SURVEY 8(d)) x N/2 unknowns per colour launch; duration = HIP-event time of the timed region / launches"},
             "finite": finite,
         }
