@@ -86,7 +86,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=512, help="grid points per direction (default: the BASELINE 512^3)")
+    ap.add_argument("--grid-n", dest="n", type=int, default=512, help="grid points per direction (default: the BASELINE 512^3)")
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=256)
@@ -100,15 +100,23 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # rehearsal on a one-GPU box: PMG_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and bootstraps over gloo (RCCL
+    # cannot run two ranks on one device); the sweep kernels, the schedule and the "ipc" halo transport are the real ones
+    share = os.environ.get("PMG_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from parmgmc_amd.dist import DistGridSampler
 
     n = args.n
-    smp = DistGridSampler(n, n, n, 10.0, rank, world, omega=args.omega)
+    smp = DistGridSampler(n, n, n, 10.0, rank, world, omega=args.omega, transport="ipc" if (share and world > 1) else None)
     g = smp.grid
     nat_b = torch.ones(g.n, dtype=torch.float64, device="cuda")
     b = g.to_cvec(nat_b)
@@ -131,7 +139,7 @@ def main() -> None:
     barrier()
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream is the one passed to the C-ABI)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
