@@ -91,7 +91,7 @@ def test_cvec_roundtrip_and_padding():
         assert np.count_nonzero(h) == x.size and np.isclose(np.sort(h[h != 0]), np.sort(x)).all()
 
 
-@pytest.mark.parametrize("grid", [(9, 9, 1, 10.0), (6, 5, 4, 2.0), (33, 7, 3, 0.5), (70, 3, 2, 1.0)])
+@pytest.mark.parametrize("grid", [(9, 9, 1, 10.0), (6, 5, 4, 2.0), (33, 7, 3, 0.5), (70, 3, 2, 1.0), (128, 128, 1, 10.0)])  # the last one is BASELINE config 0 (ex1.c at 128x128)
 def test_noisy_chain_matches_oracle(grid):
     """PCApplyRichardson_MulticolorGibbs / _SORGibbs sample loop with in-kernel Philox + Box-Muller noise vs
     the oracle (libm log/cos/sin): tolerance 1e-13 relative to max|y| (device log/sincospi differ from glibc in
