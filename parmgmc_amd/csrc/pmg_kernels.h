@@ -88,6 +88,17 @@ int pmgk_q1_prolong_add(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, co
 /* dense lower Cholesky in place + W = L^-1 on the device (npad multiple of 32; MFMA f64 trailing updates) */
 int pmgk_potrf_inverse(int32_t npad, double *A_colmajor, double *W_colmajor, double *Dinv_scratch, int *info_dev, void *stream);
 int pmgk_pack_rowmajor(int32_t n, const double *in_colmajor, int64_t ld, int transpose, double *out_rowmajor, void *stream);
+/* class-stencil form of a 27-point (9-point) Galerkin operator on an nx*ny*nz grid: coef[27*cls + e], cls = position
+   class (first / interior / last per direction), e = 9(dz+1) + 3(dy+1) + (dx+1); idiag = (1/d)*omega, sqrtdiag per
+   class; device arrays */
+typedef struct {
+  int32_t       nx, ny, nz;
+  const double *coef, *idiag, *sqrtdiag;
+} pmgk_st27;
+int pmgk_st27_sweep(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream);
+int pmgk_st27_residual(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream);
+int pmgk_st27_restrict(int nfx, int nfy, int nfz, int ncx, int ncy, int ncz, const double *r, double *bc, void *stream);
+int pmgk_st27_prolong_add(int nfx, int nfy, int nfz, int ncx, int ncy, int ncz, const double *ec, double *x, void *stream);
 /* triangular matrix-vector products of the coarse exact sampler (row-major n x n, lower or upper part) */
 int pmgk_tri_gemv(int32_t n, int upper, const double *M, const double *x, const double *add, double *out, void *stream);
 /* low-rank (MATLRC) pieces: M is n x k column-major with leading dimension ld, k <= 64 */

@@ -41,6 +41,10 @@ typedef struct {
   /* transfers to the next coarser level, in layout numbering on the device */
   int32_t  P_nrows, R_nrows;
   int32_t *cpos_dev; /* grid level only: layout position of every point of the next coarser level */
+  /* class-stencil form of a structured Galerkin level (natural-order vectors) */
+  int       is_st27, nat_transfer; /* nat_transfer: this level and the next coarser one are both in natural order */
+  pmgk_st27 st;
+  double   *st_coef, *st_idiag, *st_sqrtd, *st_sqrtd_scaled;
   int32_t *P_rowpos, *P_rowptr, *P_col, *R_rowpos, *R_rowptr, *R_col;
   double  *P_val, *R_val;
   /* optional host copies (natural numbering) for inspection */
@@ -384,6 +388,7 @@ static pmg_status upload_transfer(const hcsr *M, const int32_t *rowpos_of, const
 }
 
 static pmg_status upload_transfer(const hcsr *M, const int32_t *rowpos_of, const int32_t *colpos_of, int32_t **rowpos, int32_t **rowptr, int32_t **col, double **val);
+static int        st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_status *st);
 
 static pmg_status mgmc_setup_user(pmg_mgmc h)
 {
@@ -494,7 +499,12 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
     const int is_coarsest = (l - 1 == 0);
     pos[l - 1]            = (int32_t *)malloc(sizeof(int32_t) * (size_t)Cc->n);
     PMG_CHECK(pos[l - 1], PMG_ERR_MEM, "out of host memory");
-    if (!is_coarsest || h->coarse_type == 1) {
+    pmg_status st27_status = PMG_SUCCESS;
+    if ((!is_coarsest || h->coarse_type == 1) && !getenv("PMG_MG_NO_STENCIL") && st27_from_csr(Cc, &Ac, h->omega, &st27_status)) {
+      Cc->ld = Cc->n; /* natural order */
+      for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q;
+    } else if (!is_coarsest || h->coarse_type == 1) {
+      PMG_CALL(st27_status);
       int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)Cc->n);
       PMG_CHECK(col, PMG_ERR_MEM, "out of host memory");
       /* parity colouring (i&1) + 2(j&1) + 4(k&1), compressed to consecutive colours: valid for the 9/27-point box */
@@ -521,9 +531,13 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
       for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q;
     }
     if (is_coarsest && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr(Cc->n, Ac.rp, Ac.ci, Ac.v, &h->chol));
-    /* transfers: matrix-free Q1 kernels from the grid level, CSR products in layout numbering below it */
+    /* transfers: matrix-free Q1 kernels from the grid level and between natural-order levels, CSR products in
+       layout numbering otherwise */
+    const int coarse_natural = Cc->is_st27 || (is_coarsest && h->coarse_type == 0);
     if (U->is_grid && !getenv("PMG_MG_CSR_TRANSFERS")) {
       PMG_CALL(pmg_dev_upload((void **)&U->cpos_dev, pos[l - 1], sizeof(int32_t) * (size_t)Cc->n));
+    } else if (U->is_st27 && coarse_natural && !getenv("PMG_MG_CSR_TRANSFERS")) {
+      U->nat_transfer = 1;
     } else {
       U->P_nrows = P.nr;
       U->R_nrows = R.nr;
@@ -596,6 +610,82 @@ pmg_status pmg_mgmc_get_level_matrix(pmg_mgmc h, int32_t level, int which, int32
   return PMG_SUCCESS;
 }
 
+/* Try to express the CSR operator of a structured level as 27 position-class stencils; returns 1 if every row equals
+   its class stencil bit for bit (always the case for Galerkin operators of the constant-coefficient fine operator),
+   0 otherwise (the caller keeps the sliced-ELL form). */
+static int st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_status *st)
+{
+  *st = PMG_SUCCESS;
+  double coef[27 * 27], dg[27];
+  int    have[27];
+  memset(coef, 0, sizeof coef);
+  memset(have, 0, sizeof have);
+  const int nx = Lv->nx, ny = Lv->ny, nz = Lv->nz;
+  for (int32_t k = 0; k < nz; ++k)
+    for (int32_t j = 0; j < ny; ++j)
+      for (int32_t i = 0; i < nx; ++i) {
+        const int32_t row = i + nx * (j + ny * k);
+        const int     cls = (i == 0 ? 0 : (i == nx - 1 ? 2 : 1)) + 3 * (j == 0 ? 0 : (j == ny - 1 ? 2 : 1)) + 9 * (k == 0 ? 0 : (k == nz - 1 ? 2 : 1));
+        double        loc[27];
+        memset(loc, 0, sizeof loc);
+        int32_t expect = 0;
+        for (int dz = -1; dz <= 1; ++dz)
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+              if (i + dx >= 0 && i + dx < nx && j + dy >= 0 && j + dy < ny && k + dz >= 0 && k + dz < nz) ++expect;
+        if (A->rp[row + 1] - A->rp[row] != expect) return 0; /* not the full in-domain 27-box */
+        for (int32_t q = A->rp[row]; q < A->rp[row + 1]; ++q) {
+          const int32_t c = A->ci[q], ci = c % nx, cj = (c / nx) % ny, ck = c / (nx * ny);
+          const int     dx = ci - i, dy = cj - j, dz = ck - k;
+          if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) return 0;
+          loc[9 * (dz + 1) + 3 * (dy + 1) + (dx + 1)] = A->v[q];
+        }
+        if (!have[cls]) {
+          memcpy(coef + 27 * cls, loc, sizeof loc);
+          have[cls] = 1;
+        } else if (memcmp(coef + 27 * cls, loc, sizeof loc) != 0) {
+          return 0;
+        }
+      }
+  double idg[27], sq[27], sqs[27];
+  const double sc = sqrt((2 - omega) / omega);
+  for (int c = 0; c < 27; ++c) {
+    dg[c] = have[c] ? coef[27 * c + 13] : 1.0;
+    const double t = 1.0 / dg[c];
+    idg[c]         = t * omega;            /* MCSORUpdateIDiag, src/mc_sor.c:114-124 */
+    sq[c]          = sqrt(fabs(dg[c]));    /* src/pc_mcgibbs.c:149 */
+    sqs[c]         = sq[c] * sc;
+  }
+  *st = pmg_dev_upload((void **)&Lv->st_coef, coef, sizeof coef);
+  if (!*st) *st = pmg_dev_upload((void **)&Lv->st_idiag, idg, sizeof idg);
+  if (!*st) *st = pmg_dev_upload((void **)&Lv->st_sqrtd, sq, sizeof sq);
+  if (!*st) *st = pmg_dev_upload((void **)&Lv->st_sqrtd_scaled, sqs, sizeof sqs);
+  if (*st) return 0;
+  Lv->st.nx    = nx;
+  Lv->st.ny    = ny;
+  Lv->st.nz    = nz;
+  Lv->st.coef  = Lv->st_coef;
+  Lv->st.idiag = Lv->st_idiag;
+  Lv->is_st27  = 1;
+  return 1;
+}
+
+/* `its` samples of the level sampler on a class-stencil level (same draw numbering as pmg_mcsor_sample_layout) */
+static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, uint64_t *ctr, void *stream)
+{
+  pmgk_st27 S = Lv->st;
+  S.sqrtdiag  = h->scaled ? Lv->st_sqrtd_scaled : Lv->st_sqrtd;
+  for (int it = 0; it < its; ++it) {
+    if (h->sweep_type == PMG_SOR_SYMMETRIC_SWEEP) {
+      PMG_KERNEL(pmgk_st27_sweep(&S, 0, h->omega, 1, seed, (*ctr)++, Lv->b, Lv->x, stream));
+      PMG_KERNEL(pmgk_st27_sweep(&S, 1, h->omega, 1, seed, (*ctr)++, Lv->b, Lv->x, stream));
+    } else {
+      PMG_KERNEL(pmgk_st27_sweep(&S, h->sweep_type == PMG_SOR_BACKWARD_SWEEP, h->omega, 1, seed, (*ctr)++, Lv->b, Lv->x, stream));
+    }
+  }
+  return PMG_SUCCESS;
+}
+
 /* per-level noise seed: levels draw from independent streams */
 static uint64_t level_seed(uint64_t seed, int level) { return seed + 0x9E3779B97F4A7C15ull * (uint64_t)(level + 1); }
 
@@ -603,6 +693,7 @@ static pmg_status mg_smooth(pmg_mgmc h, int l, uint64_t seed, uint64_t *ctr, voi
 {
   mg_level *Lv = &h->lv[l];
   if (Lv->is_grid) PMG_CALL(pmg_grid_sample_cvec(Lv->g, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
+  else if (Lv->is_st27) PMG_CALL(st27_sample(h, Lv, h->nu, level_seed(seed, l), ctr, stream));
   else PMG_CALL(pmg_mcsor_sample_layout(Lv->mc, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
   return PMG_SUCCESS;
 }
@@ -619,11 +710,14 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, void *st
     PMG_HIP(hipMemsetAsync(Lv->x, 0, sizeof(double) * (size_t)Lv->ld, (hipStream_t)stream));
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
+    else if (Lv->is_st27) PMG_KERNEL(pmgk_st27_residual(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
     else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
     if (Lv->cpos_dev) { /* MatRestrict, matrix-free */
       pmgk_grid_layout GL;
       PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
       PMG_KERNEL(pmgk_q1_restrict(&GL, Cc->nx, Cc->ny, Cc->nz, Lv->cpos_dev, Lv->r, Cc->b, stream));
+    } else if (Lv->nat_transfer) {
+      PMG_KERNEL(pmgk_st27_restrict(Lv->nx, Lv->ny, Lv->nz, Cc->nx, Cc->ny, Cc->nz, Lv->r, Cc->b, stream));
     } else {
       PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, Lv->r, Cc->b, 0, stream)); /* MatRestrict */
     }
@@ -634,7 +728,8 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, void *st
       PMG_CALL(pmg_chol_sample(h->chol, C0->b, C0->x, 1, level_seed(seed, 0), ctr[0], stream));
     } else {
       PMG_HIP(hipMemsetAsync(C0->x, 0, sizeof(double) * (size_t)C0->ld, (hipStream_t)stream));
-      PMG_CALL(pmg_mcsor_sample_layout(C0->mc, C0->b, C0->x, h->coarse_its, h->scaled, level_seed(seed, 0), ctr[0], &ctr[0], stream));
+      if (C0->is_st27) PMG_CALL(st27_sample(h, C0, h->coarse_its, level_seed(seed, 0), &ctr[0], stream));
+      else PMG_CALL(pmg_mcsor_sample_layout(C0->mc, C0->b, C0->x, h->coarse_its, h->scaled, level_seed(seed, 0), ctr[0], &ctr[0], stream));
     }
   }
   for (int l = 1; l <= top; ++l) {
@@ -643,6 +738,8 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, void *st
       pmgk_grid_layout GL;
       PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
       PMG_KERNEL(pmgk_q1_prolong_add(&GL, Cc->nx, Cc->ny, Cc->nz, Lv->cpos_dev, Cc->x, Lv->x, stream));
+    } else if (Lv->nat_transfer) {
+      PMG_KERNEL(pmgk_st27_prolong_add(Lv->nx, Lv->ny, Lv->nz, Cc->nx, Cc->ny, Cc->nz, Cc->x, Lv->x, stream));
     } else {
       PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, Cc->x, Lv->x, 1, stream)); /* MatInterpolateAdd */
     }
@@ -703,6 +800,10 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
     pmg_dev_free(Lv->x);
     pmg_dev_free(Lv->r);
     pmg_dev_free(Lv->cpos_dev);
+    pmg_dev_free(Lv->st_coef);
+    pmg_dev_free(Lv->st_idiag);
+    pmg_dev_free(Lv->st_sqrtd);
+    pmg_dev_free(Lv->st_sqrtd_scaled);
     pmg_dev_free(Lv->P_rowpos);
     pmg_dev_free(Lv->P_rowptr);
     pmg_dev_free(Lv->P_col);
