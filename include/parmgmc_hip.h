@@ -243,6 +243,11 @@ pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc mg, int32_t level, int32_t 
 pmg_status pmg_mgmc_set_smoother(pmg_mgmc mg, int scaled, double omega, int sweep_type, int32_t its);
 /* -mg_coarse_pc_type cholsampler (type 0) | Gibbs sweeps with -mg_coarse_ksp_max_it its (type 1) */
 pmg_status pmg_mgmc_set_coarse(pmg_mgmc mg, int type, int32_t its);
+/* literal != 0: every sample computes w = b - A y, work = MG(w), y += work exactly as src/pc_gamgmc.c:253-256 writes
+   it.  Default (0): the same V-cycle run in place on (b, y) -- for stationary linear sweeps S(b, y) = y + S(b - A y, 0)
+   with the same noise, so both are the same chain up to rounding; the in-place form saves one fine residual, one
+   axpy and one memset per sample. */
+pmg_status pmg_mgmc_set_correction_form(pmg_mgmc mg, int literal);
 /* keep host copies of the Galerkin operators and interpolations for pmg_mgmc_get_level_matrix */
 pmg_status pmg_mgmc_set_keep_host(pmg_mgmc mg, int keep);
 /* PCSetUp(pg->mg) + PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:145-225, :352-353).  Synchronous. */

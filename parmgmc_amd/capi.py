@@ -134,6 +134,7 @@ _sig = {
     "pmg_mgmc_set_smoother": (_int, [_vp, _int, _dbl, _int, _i32]),
     "pmg_mgmc_set_coarse": (_int, [_vp, _int, _i32]),
     "pmg_mgmc_set_keep_host": (_int, [_vp, _int]),
+    "pmg_mgmc_set_correction_form": (_int, [_vp, _int]),
     "pmg_mgmc_setup": (_int, [_vp]),
     "pmg_mgmc_get_num_levels": (_int, [_vp, C.POINTER(_i32)]),
     "pmg_mgmc_get_level_dims": (_int, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),

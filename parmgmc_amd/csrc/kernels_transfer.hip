@@ -43,20 +43,35 @@ __global__ __launch_bounds__(256) void q1_restrict_kernel(pmgk_grid_layout L, in
   bc[cpos[I + ncx * (J + ncy * K)]] = s;
 }
 
-// x[pos(i,j,k)] += sum over the <= 8 coarse points interpolating fine point (i,j,k), ascending coarse index
-__global__ __launch_bounds__(256) void q1_prolong_add_kernel(pmgk_grid_layout L, int ncx, int ncy, int ncz, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ ec, double *__restrict__ x)
+// x += P e_c on the colour-partitioned fine vector: thread = two consecutive same-colour points (one 16-byte
+// read-modify-write), blocks of 64 lanes x 4 lines like the sweep; up to 8 coarse reads per point (L2-resident),
+// summed in ascending coarse index.
+__device__ __forceinline__ double q1_interp_point(int i, int j, int k, int ncx, int ncy, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ ec)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-  if (i >= L.nx) return;
-  const int I0 = rx ? i >> 1 : i, J0 = ry ? j >> 1 : j, K0 = rz ? k >> 1 : k;
-  const int mx = (rx && (i & 1)) ? 2 : 1, my = (ry && (j & 1)) ? 2 : 1, mz = (rz && (k & 1)) ? 2 : 1;
-  const double wx = mx == 2 ? 0.5 : 1.0, wy = my == 2 ? 0.5 : 1.0, wz = mz == 2 ? 0.5 : 1.0;
-  double s = 0.0;
+  const int    I0 = rx ? i >> 1 : i, J0 = ry ? j >> 1 : j, K0 = rz ? k >> 1 : k;
+  const int    mx = (rx && (i & 1)) ? 2 : 1, my = (ry && (j & 1)) ? 2 : 1, mz = (rz && (k & 1)) ? 2 : 1;
+  const double w  = (mx == 2 ? 0.5 : 1.0) * (my == 2 ? 0.5 : 1.0) * (mz == 2 ? 0.5 : 1.0);
+  double       s  = 0.0;
   for (int c = 0; c < mz; ++c)
     for (int bq = 0; bq < my; ++bq)
-      for (int a = 0; a < mx; ++a) s = s + (wx * wy * wz) * ec[cpos[(I0 + a) + ncx * ((J0 + bq) + ncy * (K0 + c))]];
-  const int64_t p = cvec_pos(L, i, j, k);
-  x[p]            = x[p] + s;
+      for (int a = 0; a < mx; ++a) s = s + w * ec[cpos[(I0 + a) + ncx * ((J0 + bq) + ncy * (K0 + c))]];
+  return s;
+}
+
+typedef double d2t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void q1_prolong_add_kernel(pmgk_grid_layout L, int ncx, int ncy, int ncz, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ ec, double *__restrict__ x)
+{
+  const int t = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z >> 1, c = blockIdx.z & 1;
+  if (j >= L.ny || 2 * t >= L.sx) return;
+  const int p  = (c + j + k + L.kz0) & 1;
+  const int i0 = 4 * t + p, i1 = i0 + 2;
+  if (i0 >= L.nx) return;
+  double       *px = x + (int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + 2 * t;
+  d2t           v  = *reinterpret_cast<d2t *>(px);
+  v.x              = v.x + q1_interp_point(i0, j, k, ncx, ncy, rx, ry, rz, cpos, ec);
+  if (i1 < L.nx) v.y = v.y + q1_interp_point(i1, j, k, ncx, ncy, rx, ry, rz, cpos, ec);
+  *reinterpret_cast<d2t *>(px) = v;
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
@@ -74,7 +89,7 @@ extern "C" int pmgk_q1_restrict(const pmgk_grid_layout *L, int ncx, int ncy, int
 extern "C" int pmgk_q1_prolong_add(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *ec, double *x_cvec, void *stream)
 {
   const int  rx = ncx != L->nx, ry = ncy != L->ny, rz = ncz != L->nz;
-  const dim3 block(64), grid((L->nx + 63) / 64, L->ny, L->nz);
+  const dim3 block(64, 4), grid((L->sx / 2 + 63) / 64, (L->ny + 3) / 4, 2 * L->nz);
   hipLaunchKernelGGL(q1_prolong_add_kernel, grid, block, 0, (hipStream_t)stream, *L, ncx, ncy, ncz, rx, ry, rz, cpos, ec, x_cvec);
   return launch_status();
 }

@@ -260,6 +260,9 @@ class MGMC:
     def set_smoother(self, scaled: bool, omega: float = 1.0, sweep_type: int = capi.SOR_FORWARD_SWEEP, its: int = 1):
         check(lib.pmg_mgmc_set_smoother(self._h, int(scaled), omega, sweep_type, its))
 
+    def set_correction_form(self, literal: bool):
+        check(lib.pmg_mgmc_set_correction_form(self._h, int(literal)))
+
     def set_coarse(self, kind: str = "cholsampler", its: int = 1):
         check(lib.pmg_mgmc_set_coarse(self._h, {"cholsampler": 0, "gibbs": 1}[kind], its))
 

@@ -117,8 +117,9 @@ def oracle_chain(grid, kappa, levels, b, y0, its, seed, counter0, guesszero, nu=
     return out
 
 
+@pytest.mark.parametrize("literal", [False, True], ids=["in_place", "correction_form"])
 @pytest.mark.parametrize("grid,levels", [((9, 9, 1), 3), ((9, 5, 5), 2), ((17, 9, 9), 3)])
-def test_mgmc_chain_matches_oracle(grid, levels):
+def test_mgmc_chain_matches_oracle(grid, levels, literal):
     """The whole sampler against the oracle's restatement of src/pc_gamgmc.c:227-264 + PCMG, same noise streams:
     tolerance 1e-11 relative (Galerkin entries / residual sums are computed in a different order; noise 1e-13)."""
     from parmgmc_amd import MGMC
@@ -127,7 +128,9 @@ def test_mgmc_chain_matches_oracle(grid, levels):
     rng = np.random.default_rng(3)
     n = int(np.prod(grid))
     b, y0 = rng.standard_normal(n), rng.standard_normal(n)
-    mg = MGMC(*grid, kappa, levels).setup()
+    mg = MGMC(*grid, kappa, levels)
+    mg.set_correction_form(literal)  # both forms are the chain of src/pc_gamgmc.c:242-259 (identical up to rounding)
+    mg.setup()
     seen = []
     yd = dev(y0)
     nxt = mg.sample(dev(b), yd, 3, seed=0xCAFE, counter0=2, guesszero=False, callback=lambda it, y: seen.append(host(y).copy()))
