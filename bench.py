@@ -81,6 +81,30 @@ def cpu_baseline(nsub: int = 256, nfull: int = 512, samples: int = 8) -> dict:
     }
 
 
+def mgmc_secondary(n: int = 257, levels: int = 5, its: int = 20) -> dict:
+    """Secondary line (BASELINE config 1, "256^3 4-level V-cycle Gibbs, 1 MI355X", on the PETSc-coarsenable 257^3):
+    samples/s of the Multigrid Monte Carlo chain (PCGAMGMC defaults: sorgibbs 1+1 sweeps per level, exact coarse
+    sampler on 17^3).  Not the headline metric."""
+    import torch
+
+    from parmgmc_amd import MGMC
+
+    t0 = time.perf_counter()
+    mg = MGMC(n, n, n, 10.0, levels).setup()
+    setup_s = time.perf_counter() - t0
+    b = torch.ones(n ** 3, dtype=torch.float64, device="cuda")
+    y = torch.zeros(n ** 3, dtype=torch.float64, device="cuda")
+    ctr = mg.sample(b, y, 3, seed=0xCAFE)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    mg.sample(b, y, its, seed=0xCAFE, counter0=ctr)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / its
+    return {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample (sorgibbs 1+1, cholsampler on {(n - 1) // 2 ** (levels - 1) + 1}^3)", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "setup_s": setup_s, "model_GBps_at_160B_per_unknown": 160 * n ** 3 / ms / 1e6, "finite": bool(torch.isfinite(y).all().item())}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +114,7 @@ def main() -> None:
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=256)
+    ap.add_argument("--no-mgmc", action="store_true", help="skip the secondary V-cycle line")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +195,10 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None, "kernel": "grid_color_sweep_kernel", "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_us": t_launch * 1e6, "note": "24 B/unknown/sweep (read y, write y, read b once; SURVEY 8(d)) x N/2 unknowns per colour launch; duration = HIP-event time of the timed region / launches"},
             "finite": finite,
         }
+        if world == 1 and not args.no_mgmc:
+            del b, y
+            torch.cuda.empty_cache()
+            out["secondary_mgmc"] = mgmc_secondary()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, n)
         print(json.dumps(out), flush=True)
