@@ -14,7 +14,7 @@ extern "C" {
    i = 2m + p, p = (c+j+kg)&1, and sit at m = 0,1,...  One ghost plane below and one above the nz owned
    planes hold the neighbouring device's boundary planes (multi-GPU) and are never read at a physical
    boundary.  Element (c, k, j, m) lives at  c*cs + (k+1)*sp + j*sx + m.  sx is a multiple of 16 doubles
-   (128 B) so that every line starts on a cache line; pad slots are zero and never written. */
+   (128 B) so that every line starts on a cache line; pad slots hold zeros (the sweep stores 0 there). */
 typedef struct {
   int32_t nx, ny, nz;  /* owned extent (nz = owned planes) */
   int32_t kz0, nzg;    /* global index of owned plane 0, global number of planes */

@@ -162,25 +162,4 @@ __device__ __forceinline__ void normal_pair(uint32_t c0, uint32_t c1, uint32_t c
   z1 = radius * s;
 }
 
-// --- stock-libm variant kept for A/B timing (PMG_GRID_VARIANT=0) ---
-// 53-bit uniform in (0,1]: ((x >> 11) + 1) * 2^-53, x = hi:lo.  Never 0, so ln(u) is finite (the reference's
-// PetscRandom may return 0 and then yields inf, src/parmgmc.c:103-106).
-__device__ __forceinline__ double u53_d(uint32_t lo, uint32_t hi)
-{
-  const uint64_t x = (((uint64_t)hi << 32) | lo) >> 11;
-  return (double)(x + 1) * 0x1.0p-53;
-}
-
-// One Box-Muller pair from one Philox block.  z0 = r cos(2 pi u2), z1 = r sin(2 pi u2).
-__device__ __forceinline__ void normal_pair_ocml(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, double &z0, double &z1)
-{
-  const Philox4 p  = philox4x32_10(c0, c1, c2, c3, k0, k1);
-  const double  u1 = u53_d(p.r0, p.r1), u2 = u53_d(p.r2, p.r3);
-  const double  radius = sqrt(-2.0 * log(u1));
-  double        s, c;
-  sincospi(2.0 * u2, &s, &c); // = sin/cos(2 pi u2) without rounding 2 pi u2 first
-  z0 = radius * c;
-  z1 = radius * s;
-}
-
 } // namespace pmg
