@@ -208,6 +208,9 @@ typedef struct pmg_chol_s *pmg_chol;
 /* PCSetUp_CholSampler dense branch: MatConvert to dense + potrf('L').  Host CSR of an SPD matrix; returns
    PMG_ERR_MAT_CH_ZRPVT naming the failing leading minor like src/pc_chols.c:190.  Synchronous. */
 pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host, pmg_chol *ch);
+/* the same sampler for a MATLRC operator A + B S B^T (src/pc_chols.c:119-153: the update is added to the matrix
+   before it is factored); B is n x k column-major, S the k diagonal entries, both on the host */
+pmg_status pmg_chol_create_csr_lowrank(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int32_t k, const double *B_host, const double *S_host, pmg_chol *out);
 /* the lower factor L, column-major n*n on the host (upper part zero) */
 pmg_status pmg_chol_get_factor(pmg_chol ch, double *L_colmajor_host);
 /* PCApply_CholSampler (src/pc_chols.c:262-291): y = L^-T (L^-1 b + xi), xi = row-stream normals of
@@ -248,6 +251,11 @@ pmg_status pmg_mgmc_set_coarse(pmg_mgmc mg, int type, int32_t its);
    with the same noise, so both are the same chain up to rounding; the in-place form saves one fine residual, one
    axpy and one memset per sample. */
 pmg_status pmg_mgmc_set_correction_form(pmg_mgmc mg, int literal);
+/* MATLRC fine operator A + B S B^T (examples/ex4.c): PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:157-196) gives every
+   level the operator A_l + B_l S B_l^T, B_{l-1} = P_l^T B_l, for its sampler and its residual; the coarse Cholesky
+   sampler factors the explicit sum (src/pc_chols.c:119-153).  B: n_fine x k column-major in the finest level's
+   natural numbering, S: k entries, host arrays (copied).  Call after the level operators are known, before set-up. */
+pmg_status pmg_mgmc_set_lowrank(pmg_mgmc mg, int32_t k, const double *B_host, const double *S_host);
 /* keep host copies of the Galerkin operators and interpolations for pmg_mgmc_get_level_matrix */
 pmg_status pmg_mgmc_set_keep_host(pmg_mgmc mg, int keep);
 /* PCSetUp(pg->mg) + PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:145-225, :352-353).  Synchronous. */

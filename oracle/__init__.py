@@ -511,3 +511,30 @@ def lrc_gibbs_samples(A: CSR, colors, B, S, b, y0, its, noise_fn, eta_fn, omega=
             draw += 1
             y = lrc_mcsor_apply(A, colors, B, Bb_f, Bb_b, w, y, omega, d)
     return y
+
+
+class LRCOperator:
+    """MATLRC: the operator A + B diag(S) B^T applied as MatMult_LRC does (A x first, then the rank-k term);
+    stands in for levels[l]["A"] in vcycle / gamgmc_richardson."""
+
+    def __init__(self, A, B: np.ndarray, S: np.ndarray):
+        self.A, self.B, self.S = A, np.asarray(B, np.float64), np.asarray(S, np.float64)
+        self.shape = A.shape
+
+    def __matmul__(self, x):
+        return self.A @ x + self.B @ (self.S * (self.B.T @ x))
+
+    def dense(self) -> np.ndarray:
+        A = self.A.toarray() if sp.issparse(self.A) else np.asarray(self.A)
+        return A + self.B @ np.diag(self.S) @ self.B.T
+
+
+def lrc_level_factors(levels, B: np.ndarray):
+    """PCGAMGMC_SetUpHierarchy (reference src/pc_gamgmc.c:166-180): B_{l-1} = P_l^T B_l from the finest level down;
+    returns [B_0, ..., B_top]."""
+    top = len(levels) - 1
+    out = [None] * (top + 1)
+    out[top] = np.asarray(B, np.float64)
+    for l in range(top, 0, -1):
+        out[l - 1] = levels[l]["P"].T @ out[l]
+    return out

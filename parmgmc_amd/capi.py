@@ -124,6 +124,7 @@ _sig = {
     "pmg_dist_sample_cvec": (_int, [_vp, _vp, _vp, _i32, _int, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_dist_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_chol_create_csr": (_int, [_i32, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pmg_chol_create_csr_lowrank": (_int, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, C.POINTER(_vp)]),
     "pmg_chol_get_factor": (_int, [_vp, _vp]),
     "pmg_chol_sample": (_int, [_vp, _vp, _vp, _int, _u64, _u64, _vp]),
     "pmg_chol_destroy": (_int, [C.POINTER(_vp)]),
@@ -134,6 +135,7 @@ _sig = {
     "pmg_mgmc_set_smoother": (_int, [_vp, _int, _dbl, _int, _i32]),
     "pmg_mgmc_set_coarse": (_int, [_vp, _int, _i32]),
     "pmg_mgmc_set_keep_host": (_int, [_vp, _int]),
+    "pmg_mgmc_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_mgmc_set_correction_form": (_int, [_vp, _int]),
     "pmg_mgmc_setup": (_int, [_vp]),
     "pmg_mgmc_get_num_levels": (_int, [_vp, C.POINTER(_i32)]),

@@ -20,10 +20,18 @@ struct pmg_chol_s {
 
 pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, pmg_chol *out)
 {
+  return pmg_chol_create_csr_lowrank(n, rowptr, colidx, vals, 0, NULL, NULL, out);
+}
+
+/* PCSetUp_CholSampler on a MATLRC operator (src/pc_chols.c:119-153): the factored matrix is P = A + B S B^T, formed
+   explicitly (MatMatTransposeMult + MatAXPY there; a dense rank-k accumulation here, the matrix is dense anyway). */
+pmg_status pmg_chol_create_csr_lowrank(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int32_t k, const double *B_host, const double *S_host, pmg_chol *out)
+{
   PMG_CHECK(out, PMG_ERR_ARG_NULL, "null output handle");
   *out = NULL;
   PMG_CHECK(n >= 1, PMG_ERR_ARG_OUTOFRANGE, "n = %d", n);
   PMG_CHECK(rowptr && colidx && vals, PMG_ERR_ARG_NULL, "null CSR array");
+  PMG_CHECK(k >= 0 && (k == 0 || (B_host && S_host)), PMG_ERR_ARG_NULL, "low-rank factors missing (k = %d)", k);
   const int32_t npad = (n + 31) / 32 * 32;
   PMG_CHECK((double)npad * npad * 8 * 4 < 96e9, PMG_ERR_SUP, "dense coarse sampler limited to a few tens of thousands of rows (n = %d); coarsen further", n);
   const size_t nn = (size_t)npad * npad;
@@ -31,6 +39,15 @@ pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr, const int32_t *
   PMG_CHECK(A, PMG_ERR_MEM, "out of host memory for the %d x %d coarse matrix", n, n);
   for (int32_t r = 0; r < n; ++r)
     for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) A[r + (size_t)npad * colidx[k]] = vals[k]; /* MatConvert(S, MATSEQDENSE), :184 */
+  for (int32_t c = 0; c < k; ++c) { /* + B S B^T, src/pc_chols.c:146-149 */
+    const double *bc = B_host + (size_t)n * c;
+    for (int32_t j = 0; j < n; ++j) {
+      const double f = S_host[c] * bc[j];
+      if (f == 0.0) continue;
+      double *col = A + (size_t)npad * j;
+      for (int32_t r = 0; r < n; ++r) col[r] += bc[r] * f;
+    }
+  }
   for (int32_t r = n; r < npad; ++r) A[r + (size_t)npad * r] = 1.0;
   pmg_chol ch = (pmg_chol)calloc(1, sizeof *ch);
   if (!ch) {

@@ -296,6 +296,7 @@ pmg_status pmg_grid_residual_cvec(pmg_grid g, const double *b, const double *y, 
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, 0, 0, 0, 0);
   PMG_KERNEL(pmgk_grid_residual(&g->L, &op, b, y, r, stream));
+  if (g->lrc) PMG_CALL(pmg_lrc_residual_sub(g->lrc, y, r, stream)); /* MatMult of the MATLRC operator */
   return PMG_SUCCESS;
 }
 

@@ -148,6 +148,15 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
   return PMG_SUCCESS;
 }
 
+/* r -= B (S o (B^T x)): the low-rank part of MatMult(A_post, x) in a residual r = b - A_post x (what PCMG's
+   residual operator is pointed at for MATLRC levels, src/pc_gamgmc.c:186-194) */
+pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream)
+{
+  PMG_KERNEL(pmgk_lrc_btx(l->ld, l->k, l->B, l->ld, x_lay, l->partial, l->S, l->wk, stream));
+  PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->B, l->ld, l->wk, -1.0, r_lay, r_lay, stream));
+  return PMG_SUCCESS;
+}
+
 /* y -= Bb_dir (B^T y), src/mc_sor.c:101-112 */
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
 {

@@ -434,6 +434,7 @@ pmg_status pmg_mcsor_residual(pmg_mcsor mc, const double *b, const double *y, do
   PMG_KERNEL(pmgk_permute_in(mc->S.ld, mc->S.orig, b, mc->b_p, stream));
   PMG_KERNEL(pmgk_permute_in(mc->S.ld, mc->S.orig, y, mc->y_p, stream));
   PMG_KERNEL(pmgk_sell_residual(&mc->S, mc->b_p, mc->y_p, mc->r_p, stream));
+  if (mc->lrc) PMG_CALL(pmg_lrc_residual_sub(mc->lrc, mc->y_p, mc->r_p, stream)); /* MatMult of the MATLRC operator */
   PMG_KERNEL(pmgk_permute_out(mc->S.ld, mc->S.orig, mc->r_p, r, stream));
   return PMG_SUCCESS;
 }
@@ -510,6 +511,7 @@ pmg_status pmg_mcsor_residual_layout(pmg_mcsor mc, const double *b_lay, const do
   PMG_CHECK(mc && b_lay && y_lay && r_lay, PMG_ERR_ARG_NULL, "null argument");
   PMG_CALL(mcsor_ready(mc));
   PMG_KERNEL(pmgk_sell_residual(&mc->S, b_lay, y_lay, r_lay, stream));
+  if (mc->lrc) PMG_CALL(pmg_lrc_residual_sub(mc->lrc, y_lay, r_lay, stream));
   return PMG_SUCCESS;
 }
 

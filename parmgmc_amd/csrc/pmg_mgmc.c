@@ -45,6 +45,7 @@ typedef struct {
   int       is_st27, nat_transfer; /* nat_transfer: this level and the next coarser one are both in natural order */
   pmgk_st27 st;
   double   *st_coef, *st_idiag, *st_sqrtd, *st_sqrtd_scaled;
+  pmg_lrc   lrc; /* MATLRC update of a class-stencil level (grid / sliced-ELL levels keep theirs inside g / mc) */
   int32_t *P_rowpos, *P_rowptr, *P_col, *R_rowpos, *R_rowptr, *R_col;
   double  *P_val, *R_val;
   /* optional host copies (natural numbering) for inspection */
@@ -63,6 +64,9 @@ struct pmg_mgmc_s {
   int       correction_form; /* 1: w = b - A y, y += MG(w) literally (src/pc_gamgmc.c:253-256); 0: the same cycle run in place on (b, y) */
   pmg_chol  chol;
   double   *y_lay, *b_lay;
+  /* MATLRC fine operator A + B S B^T (host copies until set-up; src/pc_gamgmc.c:157-196) */
+  int32_t   lrc_k;
+  double   *lrc_B, *lrc_S;
 };
 
 #define MG_DRAWS_PER_SAMPLE 64u
@@ -378,6 +382,81 @@ pmg_status pmg_mgmc_set_keep_host(pmg_mgmc h, int keep)
   return PMG_SUCCESS;
 }
 
+/* MATLRC fine-level operator A + B S B^T (MatCreateLRC in examples/ex4.c; PCSetUp_GAMGMC builds the hierarchy from
+   the base matrix A, src/pc_gamgmc.c:282-286).  PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:157-196) then gives every
+   level l the operator A_l + B_l S B_l^T with B_{l-1} = P_l^T B_l, for the level sampler AND the level residual; the
+   coarse Cholesky sampler factors the explicit sum (src/pc_chols.c:119-153).  B is n_fine x k column-major in the
+   finest level's natural numbering, S the k diagonal entries; both are copied.  Call before pmg_mgmc_setup. */
+pmg_status pmg_mgmc_set_lowrank(pmg_mgmc h, int32_t k, const double *B_host, const double *S_host)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(!h->is_setup, PMG_ERR_ARG_WRONGSTATE, "set the low-rank update before pmg_mgmc_setup");
+  PMG_CHECK(k >= 0 && k <= 64, PMG_ERR_ARG_OUTOFRANGE, "rank k = %d (0..64 supported)", k);
+  free(h->lrc_B);
+  free(h->lrc_S);
+  h->lrc_B = h->lrc_S = NULL;
+  h->lrc_k = 0;
+  if (k == 0) return PMG_SUCCESS;
+  PMG_CHECK(B_host && S_host, PMG_ERR_ARG_NULL, "null low-rank factor");
+  const int32_t n = h->lv[h->nlevels - 1].n;
+  PMG_CHECK(n > 0, PMG_ERR_ARG_WRONGSTATE, "set the finest level operator before the low-rank update");
+  h->lrc_B = (double *)malloc(sizeof(double) * (size_t)n * k);
+  h->lrc_S = (double *)malloc(sizeof(double) * (size_t)k);
+  PMG_CHECK(h->lrc_B && h->lrc_S, PMG_ERR_MEM, "out of host memory");
+  memcpy(h->lrc_B, B_host, sizeof(double) * (size_t)n * k);
+  memcpy(h->lrc_S, S_host, sizeof(double) * (size_t)k);
+  h->lrc_k = k;
+  return PMG_SUCCESS;
+}
+
+/* Bc = R Bf = P^T Bf column by column (MatTransposeMatMult(Ip, Bf), src/pc_gamgmc.c:177) */
+static pmg_status lrc_restrict_B(const hcsr *R, int32_t k, int32_t nf, const double *Bf, double **Bc_out)
+{
+  double *Bc = (double *)malloc(sizeof(double) * (size_t)R->nr * k);
+  PMG_CHECK(Bc, PMG_ERR_MEM, "out of host memory");
+  for (int32_t c = 0; c < k; ++c) {
+    const double *bf = Bf + (size_t)nf * c;
+    double       *bc = Bc + (size_t)R->nr * c;
+    for (int32_t r = 0; r < R->nr; ++r) {
+      double acc = 0.0;
+      for (int32_t q = R->rp[r]; q < R->rp[r + 1]; ++q) acc += R->v[q] * bf[R->ci[q]];
+      bc[r] = acc;
+    }
+  }
+  *Bc_out = Bc;
+  return PMG_SUCCESS;
+}
+
+typedef struct {
+  pmg_mgmc  h;
+  mg_level *Lv;
+} st27_det_ctx;
+
+static pmg_status st27_det_sweep(void *ctx, int dir, const double *b, double *y, void *stream)
+{
+  st27_det_ctx *c = (st27_det_ctx *)ctx;
+  PMG_KERNEL(pmgk_st27_sweep(&c->Lv->st, dir == PMG_SOR_BACKWARD_SWEEP, c->h->omega, 0, 0, 0, b, y, stream));
+  return PMG_SUCCESS;
+}
+
+/* MatCreateLRC(Ac, Bc, Sf) + KSPSetOperators on the level sampler (src/pc_gamgmc.c:178, :185-187): B_nat is the
+   level's n x k block in natural numbering */
+static pmg_status level_attach_lrc(pmg_mgmc h, mg_level *Lv, const double *B_nat)
+{
+  if (Lv->is_grid) return pmg_grid_set_lowrank(Lv->g, h->lrc_k, B_nat, h->lrc_S);
+  if (Lv->mc) return pmg_mcsor_set_lowrank(Lv->mc, h->lrc_k, B_nat, h->lrc_S);
+  if (Lv->is_st27) {
+    int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)Lv->n);
+    PMG_CHECK(pos, PMG_ERR_MEM, "out of host memory");
+    for (int32_t q = 0; q < Lv->n; ++q) pos[q] = q;
+    st27_det_ctx ctx = {h, Lv};
+    pmg_status   st  = pmg_lrc_build(&Lv->lrc, h->lrc_k, Lv->n, Lv->n, B_nat, pos, h->lrc_S, st27_det_sweep, &ctx);
+    free(pos);
+    return st;
+  }
+  return PMG_SUCCESS; /* coarsest level with the Cholesky sampler: the update goes into the factored matrix */
+}
+
 static pmg_status upload_transfer(const hcsr *M, const int32_t *rowpos_of, const int32_t *colpos_of, int32_t **rowpos, int32_t **rowptr, int32_t **col, double **val)
 {
   const int32_t nnz = M->rp[M->nr];
@@ -423,19 +502,31 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
       Lv->ld = Lv->n;
       for (int32_t q = 0; q < Lv->n; ++q) pos[l][q] = q;
     }
-    if (l == 0 && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr(Lv->n, Lv->A_user.rp, Lv->A_user.ci, Lv->A_user.v, &h->chol));
+    if (l == 0 && h->coarse_type == 0 && !h->lrc_k) PMG_CALL(pmg_chol_create_csr(Lv->n, Lv->A_user.rp, Lv->A_user.ci, Lv->A_user.v, &h->chol));
   }
-  for (int l = 1; l <= top; ++l) {
+  double *Bcur = h->lrc_B; /* level-l block of the low-rank factor, natural numbering (owned by h at the top) */
+  if (h->lrc_k) PMG_CALL(level_attach_lrc(h, &h->lv[top], Bcur));
+  for (int l = top; l >= 1; --l) {
     mg_level *U = &h->lv[l];
     hcsr      R;
     memset(&R, 0, sizeof R);
     PMG_CALL(hcsr_transpose(&U->P_user, &R));
+    if (h->lrc_k) { /* B_{l-1} = P_l^T B_l, src/pc_gamgmc.c:177-178 */
+      mg_level *Cc = &h->lv[l - 1];
+      double   *Bc = NULL;
+      PMG_CALL(lrc_restrict_B(&R, h->lrc_k, U->n, Bcur, &Bc));
+      if (Bcur != h->lrc_B) free(Bcur);
+      Bcur = Bc;
+      PMG_CALL(level_attach_lrc(h, Cc, Bcur));
+      if (l - 1 == 0 && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr_lowrank(Cc->n, Cc->A_user.rp, Cc->A_user.ci, Cc->A_user.v, h->lrc_k, Bcur, h->lrc_S, &h->chol));
+    }
     U->P_nrows = U->P_user.nr;
     U->R_nrows = R.nr;
     PMG_CALL(upload_transfer(&U->P_user, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
     PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
     hcsr_free(&R);
   }
+  if (Bcur != h->lrc_B) free(Bcur);
   for (int l = 0; l <= top; ++l) {
     free(pos[l]);
     mg_level *Lv = &h->lv[l];
@@ -491,6 +582,8 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
   }
   hcsr Aprev;
   memset(&Aprev, 0, sizeof Aprev);
+  double *Bcur = h->lrc_B; /* level-l block of the low-rank factor, natural numbering (owned by h at the top) */
+  if (h->lrc_k) PMG_CALL(level_attach_lrc(h, F, Bcur));
   for (int l = top; l >= 1; --l) {
     mg_level     *U = &h->lv[l], *Cc = &h->lv[l - 1];
     const int32_t nf[3] = {U->nx, U->ny, U->nz}, ncd[3] = {Cc->nx, Cc->ny, Cc->nz};
@@ -538,7 +631,14 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
       Cc->ld = Cc->n;
       for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q;
     }
-    if (is_coarsest && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr(Cc->n, Ac.rp, Ac.ci, Ac.v, &h->chol));
+    if (h->lrc_k) { /* B_{l-1} = P_l^T B_l and the MATLRC level operator, src/pc_gamgmc.c:177-187 */
+      double *Bc = NULL;
+      PMG_CALL(lrc_restrict_B(&R, h->lrc_k, U->n, Bcur, &Bc));
+      if (Bcur != h->lrc_B) free(Bcur);
+      Bcur = Bc;
+      PMG_CALL(level_attach_lrc(h, Cc, Bcur));
+    }
+    if (is_coarsest && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr_lowrank(Cc->n, Ac.rp, Ac.ci, Ac.v, h->lrc_k, Bcur, h->lrc_S, &h->chol));
     /* transfers: matrix-free Q1 kernels from the grid level and between natural-order levels, CSR products in
        layout numbering otherwise */
     const int coarse_natural = Cc->is_st27 || (is_coarsest && h->coarse_type == 0);
@@ -570,6 +670,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
     }
   }
   hcsr_free(&Aprev);
+  if (Bcur != h->lrc_B) free(Bcur);
   for (int l = 0; l < h->nlevels; ++l) {
     free(pos[l]);
     mg_level *Lv = &h->lv[l];
@@ -684,11 +785,13 @@ static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, 
   pmgk_st27 S = Lv->st;
   S.sqrtdiag  = h->scaled ? Lv->st_sqrtd_scaled : Lv->st_sqrtd;
   for (int it = 0; it < its; ++it) {
-    if (h->sweep_type == PMG_SOR_SYMMETRIC_SWEEP) {
-      PMG_KERNEL(pmgk_st27_sweep(&S, 0, h->omega, 1, seed, (*ctr)++, Lv->b, Lv->x, stream));
-      PMG_KERNEL(pmgk_st27_sweep(&S, 1, h->omega, 1, seed, (*ctr)++, Lv->b, Lv->x, stream));
-    } else {
-      PMG_KERNEL(pmgk_st27_sweep(&S, h->sweep_type == PMG_SOR_BACKWARD_SWEEP, h->omega, 1, seed, (*ctr)++, Lv->b, Lv->x, stream));
+    const int ndir = h->sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
+    for (int d = 0; d < ndir; ++d) {
+      const int     backward = ndir == 2 ? d : h->sweep_type == PMG_SOR_BACKWARD_SWEEP;
+      const double *rhs      = Lv->b;
+      if (Lv->lrc) PMG_CALL(pmg_lrc_rhs(Lv->lrc, Lv->b, seed, *ctr, &rhs, stream)); /* + B (sqrt(S) o eta), src/pc_mcgibbs.c:130-140 */
+      PMG_KERNEL(pmgk_st27_sweep(&S, backward, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
+      if (Lv->lrc) PMG_CALL(pmg_lrc_post(Lv->lrc, backward ? PMG_SOR_BACKWARD_SWEEP : PMG_SOR_FORWARD_SWEEP, Lv->x, stream)); /* src/mc_sor.c:101-112 */
     }
   }
   return PMG_SUCCESS;
@@ -719,7 +822,10 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     if (l < top || !top_has_guess) PMG_HIP(hipMemsetAsync(Lv->x, 0, sizeof(double) * (size_t)Lv->ld, (hipStream_t)stream));
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
-    else if (Lv->is_st27) PMG_KERNEL(pmgk_st27_residual(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
+    else if (Lv->is_st27) {
+      PMG_KERNEL(pmgk_st27_residual(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
+      if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* PCMGSetResidual(..., As[l]), src/pc_gamgmc.c:194 */
+    }
     else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
     if (Lv->cpos_dev) { /* MatRestrict, matrix-free */
       pmgk_grid_layout GL;
@@ -825,6 +931,7 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
     pmg_dev_free(Lv->st_idiag);
     pmg_dev_free(Lv->st_sqrtd);
     pmg_dev_free(Lv->st_sqrtd_scaled);
+    pmg_lrc_destroy(&Lv->lrc);
     pmg_dev_free(Lv->P_rowpos);
     pmg_dev_free(Lv->P_rowptr);
     pmg_dev_free(Lv->P_col);
@@ -839,6 +946,8 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
   pmg_chol_destroy(&h->chol);
   pmg_dev_free(h->y_lay);
   pmg_dev_free(h->b_lay);
+  free(h->lrc_B);
+  free(h->lrc_S);
   free(h->lv);
   free(h);
   *hp = NULL;

@@ -200,11 +200,18 @@ class GridMCSOR:
 class CholSampler:
     """Exact coarse sampler (reference PCCHOLSAMPLER dense path, src/pc_chols.c:174-291)."""
 
-    def __init__(self, rowptr, colidx, vals):
+    def __init__(self, rowptr, colidx, vals, B=None, S=None):
+        """B (n x k), S (k): factor the MATLRC operator A + B diag(S) B^T instead (src/pc_chols.c:119-153)."""
         rp, ci, v = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colidx, np.int32), np.ascontiguousarray(vals, np.float64)
         self.n = len(rp) - 1
         self._h = C.c_void_p()
-        check(lib.pmg_chol_create_csr(self.n, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, C.byref(self._h)))
+        if B is None:
+            check(lib.pmg_chol_create_csr(self.n, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, C.byref(self._h)))
+        else:
+            B = np.asfortranarray(B, np.float64)
+            S = np.ascontiguousarray(S, np.float64)
+            assert B.shape == (self.n, len(S))
+            check(lib.pmg_chol_create_csr_lowrank(self.n, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, B.shape[1], B.ctypes.data, S.ctypes.data, C.byref(self._h)))
 
     def factor(self) -> np.ndarray:
         out = np.zeros(self.n * self.n)
@@ -262,6 +269,13 @@ class MGMC:
 
     def set_correction_form(self, literal: bool):
         check(lib.pmg_mgmc_set_correction_form(self._h, int(literal)))
+
+    def set_lowrank(self, B, S):
+        """MATLRC fine operator A + B diag(S) B^T, propagated to every level (reference src/pc_gamgmc.c:157-196)."""
+        B = np.asfortranarray(B, np.float64)
+        S = np.ascontiguousarray(S, np.float64)
+        assert B.ndim == 2 and B.shape[1] == len(S)
+        check(lib.pmg_mgmc_set_lowrank(self._h, B.shape[1], B.ctypes.data, S.ctypes.data))
 
     def set_coarse(self, kind: str = "cholsampler", its: int = 1):
         check(lib.pmg_mgmc_set_coarse(self._h, {"cholsampler": 0, "gibbs": 1}[kind], its))
