@@ -302,6 +302,10 @@ pmg_status pmg_options_clear(void);
 /* operators: a MATSEQAIJ as borrowed host CSR, or the DMDA operator of MatAssembleShiftedLaplaceFD */
 pmg_status pmg_mat_create_csr(int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host, pmg_mat *mat);
 pmg_status pmg_mat_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa, pmg_mat *mat);
+/* MatCreateLRC(A, B, S, NULL, &Alrc) (examples/ex4.c, src/obs.c:176): A + B diag(S) B^T with B n x k column-major
+   and S k entries as borrowed host arrays; mcgibbs / sorgibbs / cholsampler / gamgmc honour it as the reference does
+   (src/mc_sor.c:572-595, src/pc_chols.c:119-153, src/pc_gamgmc.c:157-196) */
+pmg_status pmg_mat_create_lrc(pmg_mat A, int32_t k, const double *B_host, const double *S_host, pmg_mat *mat);
 pmg_status pmg_mat_get_size(pmg_mat mat, int32_t *n);
 pmg_status pmg_mat_destroy(pmg_mat *mat);
 

@@ -79,6 +79,9 @@ struct pmg_mat_s {
   const double  *vals;
   int32_t        nx, ny, nz;
   double         kappa;
+  /* MATLRC: this + B S B^T (borrowed host arrays: B n x k column-major, S k entries) */
+  int32_t        lrc_k;
+  const double  *lrc_B, *lrc_S;
 };
 
 pmg_status pmg_mat_create_csr(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, pmg_mat *out)
@@ -109,6 +112,24 @@ pmg_status pmg_mat_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa,
   m->n     = nx * ny * nz;
   m->kappa = kappa;
   *out     = m;
+  return PMG_SUCCESS;
+}
+
+/* MatCreateLRC(A, B, S, NULL, &Alrc) as examples/ex4.c and src/obs.c use it: A + B diag(S) B^T.  The result refers
+   to the same base operator (its arrays stay borrowed) and to B / S as borrowed host arrays. */
+pmg_status pmg_mat_create_lrc(pmg_mat A, int32_t k, const double *B_host, const double *S_host, pmg_mat *out)
+{
+  PMG_CHECK(A && out, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(!A->lrc_k, PMG_ERR_SUP, "nested low-rank updates");
+  PMG_CHECK(k >= 1 && k <= 64, PMG_ERR_ARG_OUTOFRANGE, "rank k = %d (1..64 supported)", k);
+  PMG_CHECK(B_host && S_host, PMG_ERR_ARG_NULL, "null low-rank factor");
+  pmg_mat m = (pmg_mat)malloc(sizeof *m);
+  PMG_CHECK(m, PMG_ERR_MEM, "out of host memory");
+  *m        = *A;
+  m->lrc_k  = k;
+  m->lrc_B  = B_host;
+  m->lrc_S  = S_host;
+  *out      = m;
   return PMG_SUCCESS;
 }
 
@@ -402,12 +423,14 @@ static pmg_status gibbs_setup(pmg_pc pc) /* PCSetUp_SORGibbs :181-262 / PCSetUp_
     PMG_CALL(pmg_grid_create(pc->pmat->nx, pc->pmat->ny, pc->pmat->nz, 0, pc->pmat->nz, pc->pmat->kappa, &d->g));
     PMG_CALL(pmg_grid_set_omega(d->g, d->omega));
     PMG_CALL(pmg_grid_set_sweep_type(d->g, d->type));
+    if (pc->pmat->lrc_k) PMG_CALL(pmg_grid_set_lowrank(d->g, pc->pmat->lrc_k, pc->pmat->lrc_B, pc->pmat->lrc_S)); /* MATLRC, src/pc_mcgibbs.c:226-243 */
   } else {
     PMG_CALL(pmg_mcsor_create_csr(pc->pmat->n, pc->pmat->rowptr, pc->pmat->colidx, pc->pmat->vals, &d->mc));
     PMG_CALL(pmg_mcsor_set_coloring(d->mc, d->coloring, NULL));
     PMG_CALL(pmg_mcsor_set_omega(d->mc, d->omega));
     PMG_CALL(pmg_mcsor_set_sweep_type(d->mc, d->type));
     PMG_CALL(pmg_mcsor_setup(d->mc));
+    if (pc->pmat->lrc_k) PMG_CALL(pmg_mcsor_set_lowrank(d->mc, pc->pmat->lrc_k, pc->pmat->lrc_B, pc->pmat->lrc_S));
   }
   return PMG_SUCCESS;
 }
@@ -544,6 +567,7 @@ static pmg_status parsor_setup(pmg_pc pc)
 {
   pc_parsor *d = (pc_parsor *)pc->data;
   parsor_reset(pc);
+  PMG_CHECK(!pc->pmat->lrc_k, PMG_ERR_SUP, "parsor works on assembled matrices (MATAIJ), not MATLRC");
   if (pc->pmat->kind == 1) { /* red-black order on the grid: a different but equally valid sweep order */
     PMG_CALL(pmg_grid_create(pc->pmat->nx, pc->pmat->ny, pc->pmat->nz, 0, pc->pmat->nz, pc->pmat->kappa, &d->g));
     PMG_CALL(pmg_grid_set_omega(d->g, d->omega));
@@ -626,7 +650,7 @@ static pmg_status chols_setup(pmg_pc pc)
   pc_chols *d = (pc_chols *)pc->data;
   chols_reset(pc);
   PMG_CHECK(pc->pmat->kind == 0, PMG_ERR_SUP, "cholsampler needs an assembled matrix");
-  return pmg_chol_create_csr(pc->pmat->n, pc->pmat->rowptr, pc->pmat->colidx, pc->pmat->vals, &d->ch);
+  return pmg_chol_create_csr_lowrank(pc->pmat->n, pc->pmat->rowptr, pc->pmat->colidx, pc->pmat->vals, pc->pmat->lrc_k, pc->pmat->lrc_B, pc->pmat->lrc_S, &d->ch); /* :119-153 */
 }
 static pmg_status chols_apply(pmg_pc pc, const double *b, double *y, void *stream) /* PCApply_CholSampler :262-291 */
 {
@@ -708,6 +732,7 @@ static pmg_status gamgmc_setup(pmg_pc pc)
   PMG_CALL(pmg_mgmc_create_dmda(pc->pmat->nx, pc->pmat->ny, pc->pmat->nz, pc->pmat->kappa, d->levels, &d->mg));
   PMG_CALL(pmg_mgmc_set_smoother(d->mg, d->smoother_mc, d->smoother_mc ? d->omega : 1.0, d->smoother_mc ? d->sweep : PMG_SOR_FORWARD_SWEEP, d->nu));
   PMG_CALL(pmg_mgmc_set_coarse(d->mg, d->coarse_kind, d->coarse_its));
+  if (pc->pmat->lrc_k) PMG_CALL(pmg_mgmc_set_lowrank(d->mg, pc->pmat->lrc_k, pc->pmat->lrc_B, pc->pmat->lrc_S)); /* src/pc_gamgmc.c:157-196 */
   return pmg_mgmc_setup(d->mg);
 }
 static pmg_status gamgmc_applyrichardson(pmg_pc pc, const double *b, double *y, int32_t its, int guesszero, int32_t *outits, void *stream)

@@ -49,6 +49,15 @@ class Mat:
         check(lib.pmg_mat_create_dmda(nx, ny, nz, kappa, C.byref(h)))
         return Mat(h)
 
+    def lrc(self, B, S) -> "Mat":
+        """MatCreateLRC(A, B, S): A + B diag(S) B^T (reference examples/ex4.c)."""
+        B = np.asfortranarray(B, np.float64)
+        S = np.ascontiguousarray(S, np.float64)
+        assert B.ndim == 2 and B.shape == (self.size, len(S))
+        h = C.c_void_p()
+        check(lib.pmg_mat_create_lrc(self._h, B.shape[1], B.ctypes.data, S.ctypes.data, C.byref(h)))
+        return Mat(h, (self, B, S))
+
     @property
     def size(self) -> int:
         n = C.c_int32()

@@ -180,3 +180,85 @@ def test_ex8_listing_smoke():
         y = dev(np.zeros(257 * 257))
         pc.ksp_solve(f, y, 100, guess_nonzero=False)
         assert bool(torch.isfinite(y).all()) and float(y.abs().max()) > 0
+
+
+def ball_observations(nx, ny, coords, radii, obsvals, sigma2):
+    """MakeObservationMats (reference src/obs.c:135-180) on the unit-square DMDA: column i = M u_i with
+    u_i = 1/vol inside the ball (src/obs.c:39-50), S = 1/sigma2, f = B (S o obsvals) (:160-178).  The P1 mass matrix
+    of the reference's DMPlex is replaced by the lumped mass h^2 of the uniform grid (the FE assembly is out of scope)."""
+    xs, ys = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), indexing="xy")
+    pts = np.stack([xs.ravel(), ys.ravel()], 1)  # natural DMDA order: x fastest
+    h2 = 1.0 / ((nx - 1) * (ny - 1))
+    B = np.zeros((nx * ny, len(radii)))
+    for i, r in enumerate(radii):
+        inside = ((pts - np.asarray(coords[2 * i:2 * i + 2])) ** 2).sum(1) < r * r
+        B[inside, i] = h2 / (np.pi * r * r)
+    S = np.full(len(radii), 1.0 / sigma2)
+    return B, S, B @ (S * np.asarray(obsvals))
+
+
+@pytest.mark.parametrize("opts,pc_type,nburn,nsamp,tol", [
+    ({"-gamgmc_mg_coarse_pc_type": "sorgibbs"}, "gamgmc", 500, 2000, 0.10),      # ex4.c:28
+    ({"-gamgmc_mg_coarse_pc_type": "mcgibbs"}, "gamgmc", 500, 2000, 0.10),       # ex4.c:31
+    ({"-gamgmc_mg_coarse_pc_type": "cholsampler"}, "gamgmc", 500, 2000, 0.10),   # ex4.c:34
+    ({"-pc_mcgibbs_symmetric": ""}, "mcgibbs", 2000, 20000, 0.05),               # ex4.c:52
+    ({}, "sorgibbs", 2000, 20000, 0.05),                                         # ex4.c:55
+])
+def test_ex4_lowrank_through_the_pc_layer(opts, pc_type, nburn, nsamp, tol):
+    """reference examples/ex4.c RUN lines with -with_lr: KSPSetOperators(ksp, MatCreateLRC(A, B, S)), the three ball
+    observations of ex4.c:150-166 (sigma2 = 1e-4), burn-in, running mean in the sample callback, relative error of the
+    posterior mean vs a direct solve <= -tol (the reference's own tolerances and sample counts)."""
+    import torch
+
+    from parmgmc_amd import pc as P
+
+    nx = ny = 17
+    kappa = 1.0
+    for k, v in opts.items():
+        P.options_set_value(k, v)
+    P.options_set_value("-pc_type", pc_type)
+    P.options_set_value("-gamgmc_pc_mg_levels", "3")  # -dm_refine_hierarchy 2
+    B, S, f = ball_observations(nx, ny, [0.25, 0.25, 0.75, 0.75, 0.25, 0.75], [0.1, 0.15, 0.1], [1.0, -1.0, 1.0], 1e-4)
+    A = P.Mat.dmda(nx, ny, 1, kappa)
+    Aop = A.lrc(B, S)  # MatCreateLRC, ex4.c:168
+    pc = P.PC()
+    pc.set_operators(Aop)
+    pc.set_from_options()
+    pc.setup()
+    b, x = dev(f), dev(np.zeros(nx * ny))
+    mean = torch.zeros_like(x)
+
+    def cb(it, y):  # SampleCallbackKSP, ex4.c:115-131
+        if it >= nburn:
+            k = it - nburn
+            mean.mul_(k / (k + 1.0)).add_(y, alpha=1.0 / (k + 1))
+
+    pc.set_sample_callback(cb, x)
+    pc.ksp_solve(b, x, nsamp, guess_nonzero=True)
+    Apost = O.shifted_laplace(nx, ny, 1, kappa).dense() + B @ np.diag(S) @ B.T
+    ex = np.linalg.solve(Apost, f)
+    err = np.linalg.norm(host(mean) - ex) / np.linalg.norm(ex)
+    assert err < tol, err
+
+
+def test_cholsampler_on_lrc_and_parsor_rejects_lrc():
+    from parmgmc_amd import PMGError
+    from parmgmc_amd import pc as P
+
+    Ah = O.shifted_laplace(9, 9, 1, 1.0)
+    B, S, f = ball_observations(9, 9, [0.5, 0.5], [0.2], [1.0], 1e-2)
+    A = P.Mat.csr(Ah.rowptr, Ah.colidx, Ah.vals).lrc(B, S)
+    pc = P.PC("cholsampler")
+    pc.set_operators(A)
+    pc.setup()
+    seed, ctr = pc.noise_state()
+    y = dev(np.zeros(81))
+    pc.apply(dev(f), y)
+    L = O.potrf_lower(Ah.dense() + B @ np.diag(S) @ B.T)  # src/pc_chols.c:119-153
+    want = O.chol_sample(L, f, O.noise_rows(81, seed, ctr))
+    assert np.abs(host(y) - want).max() / np.abs(want).max() < 1e-12
+    ps = P.PC("parsor")
+    ps.set_operators(A)
+    with pytest.raises(PMGError) as e:
+        ps.setup()
+    assert e.value.code == 56
