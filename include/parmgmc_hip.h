@@ -277,6 +277,17 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *mg);
 /* ------------------------------------------------------------------------------------------------------ */
 pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t seed, uint64_t counter, void *stream);
 
+/* ---- chain diagnostics (host arrays, host arithmetic -- as in the reference) ---------------------------------- */
+/* Autocorrelation (src/iact.c:17-47): acf[0..n) of the scalar series x[0..n) via a zero-padded FFT */
+pmg_status pmg_autocorrelation(int64_t n, const double *x_host, double *acf_host);
+/* IACT (src/iact.c:73-92; examples/ex2.c:107): integrated autocorrelation time with the automatic window
+   M >= 5 tau(M); acf_host may be NULL; *valid = (500 tau <= n), may be NULL */
+pmg_status pmg_iact(int64_t n, const double *x_host, double *tau, double *acf_host, int *valid);
+/* EstimateCovarianceMatErrors (src/stats.c:94-117; examples/ex6.c:193): samples = host rows of length n ordered
+   {sample 0 of chain 0, sample 0 of chain 1, ..., sample 1 of chain 0, ...}; errs[samples_per_chain] =
+   ||C_i - A^-1||_F / ||A^-1||_F with the unbiased covariance over the chains at sample index i */
+pmg_status pmg_estimate_covariance_errors(int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host, int32_t chains, int32_t samples_per_chain, const double *samples_host, double *errs_host);
+
 /* ------------------------------------------------------------------------------------------------------ */
 /* The registration boundary without PETSc: PCRegister / PCSetType / pc->ops / PCSetSampleCallback /        */
 /* PCSHELL / KSPRICHARDSON on raw device arrays (reference src/parmgmc.c:44-54,118-151; examples/ex1.c,     */

@@ -538,3 +538,45 @@ def lrc_level_factors(levels, B: np.ndarray):
     for l in range(top, 0, -1):
         out[l - 1] = levels[l]["P"].T @ out[l]
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# chain diagnostics
+# ------------------------------------------------------------------------------------------------
+def autocorrelation(x: np.ndarray) -> np.ndarray:
+    """Autocorrelation (reference src/iact.c:17-47): zero-pad x - mean to 2 * nextpow2(n), |FFT|^2, inverse FFT,
+    normalise by lag 0."""
+    x = np.asarray(x, np.float64)
+    n = len(x)
+    N = 1
+    while N < n:
+        N <<= 1
+    f = np.fft.fft(x - x.mean(), 2 * N)
+    c = np.fft.ifft(f * np.conj(f)).real[:n]
+    return c / c[0]
+
+
+def iact(x: np.ndarray):
+    """IACT + AutoWindow(c=5) (reference src/iact.c:49-92): returns (tau, valid)."""
+    n = len(x)
+    taus = 2 * np.cumsum(autocorrelation(x)) - 1
+    idx = np.arange(n)
+    if np.any(idx < 5 * taus):
+        ok = np.nonzero(idx >= 5 * taus)[0]
+        w = ok[0] if len(ok) else 0
+    else:
+        w = n - 1
+    return float(taus[w]), bool(500 * taus[w] <= n)
+
+
+def covariance_errors(A: CSR, samples: np.ndarray, chains: int) -> np.ndarray:
+    """EstimateCovarianceMatErrors (reference src/stats.c:94-117): samples (samples_per_chain * chains, n),
+    sample-major; unbiased covariance over chains per sample index vs A^-1, relative Frobenius error."""
+    Q = np.linalg.inv(A.dense())
+    spc = samples.shape[0] // chains
+    out = np.empty(spc)
+    for i in range(spc):
+        S = samples[i * chains:(i + 1) * chains]
+        W = S - S.mean(0)
+        out[i] = np.linalg.norm(W.T @ W / (chains - 1) - Q) / np.linalg.norm(Q)
+    return out

@@ -333,3 +333,32 @@ def vec_set_random_standard_normal(x, seed: int, counter: int = 0):
     """VecSetRandomStandardNormal (reference src/parmgmc.c:70-116) on the counter-based source."""
     check(lib.pmg_vec_set_random_standard_normal(x.numel(), _ptr(x), seed, counter, _stream()))
     return x
+
+
+def autocorrelation(x):
+    """Autocorrelation (reference src/iact.c:17-47) of a scalar series; host arrays."""
+    x = np.ascontiguousarray(x, np.float64)
+    acf = np.empty_like(x)
+    check(lib.pmg_autocorrelation(len(x), x.ctypes.data, acf.ctypes.data))
+    return acf
+
+
+def iact(x):
+    """IACT (reference src/iact.c:73-92): returns (tau, valid)."""
+    x = np.ascontiguousarray(x, np.float64)
+    tau, valid = C.c_double(), C.c_int()
+    check(lib.pmg_iact(len(x), x.ctypes.data, C.byref(tau), None, C.byref(valid)))
+    return tau.value, bool(valid.value)
+
+
+def estimate_covariance_errors(rowptr, colidx, vals, samples, chains: int):
+    """EstimateCovarianceMatErrors (reference src/stats.c:94-117); samples: (samples_per_chain * chains, n) host rows
+    ordered sample-major."""
+    rp, ci, v = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colidx, np.int32), np.ascontiguousarray(vals, np.float64)
+    S = np.ascontiguousarray(samples, np.float64)
+    n = len(rp) - 1
+    assert S.ndim == 2 and S.shape[1] == n and S.shape[0] % chains == 0
+    spc = S.shape[0] // chains
+    errs = np.empty(spc)
+    check(lib.pmg_estimate_covariance_errors(n, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, chains, spc, S.ctypes.data, errs.ctypes.data))
+    return errs
