@@ -356,6 +356,14 @@ pmg_status pmg_pc_mcgibbs_set_sweep_type(pmg_pc pc, int type);
 pmg_status pmg_pc_parsor_set_omega(pmg_pc pc, double omega);
 pmg_status pmg_pc_parsor_set_iterations(pmg_pc pc, int32_t its);
 pmg_status pmg_pc_parsor_apply_sor(pmg_pc pc, const double *b_dev, int32_t its, int zero_initial_guess, double *x_dev, void *stream);
+/* PCWOODBURY (src/woodbury.c): sampler for a MATLRC operator A + B S B^T built from any sampler of A plus a solver
+   (a PC with `apply`) of A: set-up forms G = C (S^-1 + B^T C)^-1 with C = solver(B) (:21-91) and drops the solver;
+   every sample adds B (sqrt(S) o eta) to the rhs, draws one sample of the inner sampler and applies y -= G (B^T y)
+   (:263-289).  PCWoodburySetSolver / PCWoodburySetSampler (:185-213): the woodbury PC takes over the caller's
+   reference (do not destroy the inner PC afterwards); options -pc_woodbury_solver <type>, -pc_woodbury_sampler <type>
+   create them (:245-261); inner option prefixes are "pc_woodbury_solver_" and "pc_woodbury_sampler" (sic, :208). */
+pmg_status pmg_pc_woodbury_set_solver(pmg_pc pc, pmg_pc solver);
+pmg_status pmg_pc_woodbury_set_sampler(pmg_pc pc, pmg_pc sampler);
 pmg_status pmg_pc_gamgmc_set_levels(pmg_pc pc, int32_t levels);
 /* PCSHELL: PCShellSetApply / PCShellSetContext / PCShellGetContext (examples/ex3.c:59-67,128-131) */
 pmg_status pmg_pc_shell_set_apply(pmg_pc pc, pmg_status (*apply)(pmg_pc pc, const double *x_dev, double *y_dev, void *stream));

@@ -154,6 +154,8 @@ _sig = {
     "pmg_autocorrelation": (_int, [C.c_int64, _vp, _vp]),
     "pmg_iact": (_int, [C.c_int64, _vp, C.POINTER(_dbl), _vp, C.POINTER(_int)]),
     "pmg_estimate_covariance_errors": (_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "pmg_pc_woodbury_set_solver": (_int, [_vp, _vp]),
+    "pmg_pc_woodbury_set_sampler": (_int, [_vp, _vp]),
     "pmg_mat_create_lrc": (_int, [_vp, _i32, _vp, _vp, C.POINTER(_vp)]),
     "pmg_mat_get_size": (_int, [_vp, C.POINTER(_i32)]),
     "pmg_mat_destroy": (_int, [C.POINTER(_vp)]),

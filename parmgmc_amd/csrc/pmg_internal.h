@@ -50,6 +50,7 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream);
 void       pmg_lrc_destroy(pmg_lrc *l);
+int        pmg_invert_small(int k, double *a_colmajor, double *inv); /* Gauss-Jordan, partial pivoting; a is overwritten; nonzero = singular */
 
 /* device allocation helpers (zero-filled) */
 pmg_status pmg_dev_alloc(void **p, size_t bytes);

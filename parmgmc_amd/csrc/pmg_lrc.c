@@ -41,7 +41,7 @@ void pmg_lrc_destroy(pmg_lrc *p)
 }
 
 /* in-place inverse of a small dense matrix (column-major k x k) by Gauss-Jordan with partial pivoting */
-static int invert_small(int k, double *a, double *inv)
+int pmg_invert_small(int k, double *a, double *inv)
 {
   for (int i = 0; i < k * k; ++i) inv[i] = 0.0;
   for (int i = 0; i < k; ++i) inv[i + k * i] = 1.0;
@@ -122,7 +122,7 @@ pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const d
     }
     if (st) break;
     for (int c = 0; c < k; ++c) T[c + (size_t)k * c] += 1.0 / S_host[c]; /* + S^-1, src/mc_sor.c:525-527 */
-    if (invert_small(k, T, Sb)) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "S^-1 + B^T M^-1 B is singular");
+    if (pmg_invert_small(k, T, Sb)) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "S^-1 + B^T M^-1 B is singular");
     if (!st && hipMemcpy(Sb_dev, Sb, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "upload failed");
     if (!st && pmgk_lrc_gemm_small(ld, k, l->col, ld, Sb_dev, l->Bb[d], NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed"); /* Bb = C Sb, :535 */
     if (!st && hipDeviceSynchronize() != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device error while building the low-rank correction");

@@ -43,7 +43,7 @@ pmg_status pmg_options_clear(void)
 
 static const char *opt_find(const char *prefix, const char *name)
 {
-  char full[160];
+  char full[320];
   snprintf(full, sizeof full, "-%s%s", prefix ? prefix : "", name + 1);
   for (int i = 0; i < pmg_nopts; ++i)
     if (!strcmp(pmg_opts[i].name, full)) return pmg_opts[i].value;
@@ -163,7 +163,7 @@ typedef struct {
 } pmg_pc_ops;
 
 struct pmg_pc_s {
-  char       type[32], prefix[64];
+  char       type[32], prefix[128];
   pmg_pc_ops ops;
   void      *data;
   pmg_mat    pmat; /* borrowed, like pc->pmat (src/pc_sorgibbs.c:35-38) */
@@ -701,7 +701,7 @@ static pmg_status gamgmc_destroy(pmg_pc pc)
 static pmg_status gamgmc_setfromoptions(pmg_pc pc) /* src/pc_gamgmc.c:299-366: defaults injected, overridable */
 {
   pc_gamgmc  *d = (pc_gamgmc *)pc->data;
-  char        pre[96];
+  char        pre[160];
   const char *v;
   snprintf(pre, sizeof pre, "%sgamgmc_", pc->prefix);
   if ((v = opt_find(pc->prefix, "-pc_gamgmc_mg_type")) && strcmp(v, "mg")) PMG_FAIL(PMG_ERR_SUP, "-pc_gamgmc_mg_type %s: only the geometric hierarchy (mg) on a DMDA is built here; GAMG aggregation is PETSc's", v);
@@ -816,6 +816,181 @@ pmg_status pmg_pc_shell_get_context(pmg_pc pc, void **ctx)
 }
 
 /* ---------------------------------------------------------------------------------------------------- */
+/* "woodbury" (src/woodbury.c): a sampler for A + B S B^T assembled from ANY sampler of A plus a solver   */
+/* ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+  pmg_pc  solver, sampler; /* owned */
+  pmg_mat Abase;           /* the base operator of the MATLRC matrix, owned copy of the descriptor */
+  int32_t k;
+  double *B, *G;           /* device, n x k column-major (natural numbering) */
+  double *S_sqrt, *wk, *partial, *w; /* device: sqrt|S| (k), work (64), reduction scratch, noisy rhs (n) */
+} pc_woodbury;
+
+static pmg_status woodbury_free_setup(pc_woodbury *d)
+{
+  pmg_dev_free(d->B);
+  pmg_dev_free(d->G);
+  pmg_dev_free(d->S_sqrt);
+  pmg_dev_free(d->wk);
+  pmg_dev_free(d->partial);
+  pmg_dev_free(d->w);
+  d->B = d->G = d->S_sqrt = d->wk = d->partial = d->w = NULL;
+  pmg_mat_destroy(&d->Abase);
+  return PMG_SUCCESS;
+}
+static pmg_status woodbury_reset(pmg_pc pc) /* PCReset_Woodbury :93-109 */
+{
+  pc_woodbury *d = (pc_woodbury *)pc->data;
+  woodbury_free_setup(d);
+  if (d->solver) PMG_CALL(pmg_pc_reset(d->solver));
+  if (d->sampler) PMG_CALL(pmg_pc_reset(d->sampler));
+  return PMG_SUCCESS;
+}
+static pmg_status woodbury_destroy(pmg_pc pc) /* PCDestroy_Woodbury :111-125 */
+{
+  pc_woodbury *d = (pc_woodbury *)pc->data;
+  if (d) {
+    woodbury_free_setup(d);
+    pmg_pc_destroy(&d->solver);
+    pmg_pc_destroy(&d->sampler);
+    free(d);
+    pc->data = NULL;
+  }
+  return PMG_SUCCESS;
+}
+
+/* PCWoodburySetSolver / PCWoodburySetSampler (:185-213): the inner PC gets the outer prefix plus
+   "pc_woodbury_solver_" / "pc_woodbury_sampler" (the reference appends the sampler prefix WITHOUT a trailing
+   underscore, :208 -- kept, so the option keys are the reference's).  The woodbury PC takes the reference the
+   caller held: do not destroy `inner` afterwards. */
+static pmg_status woodbury_adopt(pmg_pc pc, pmg_pc inner, int is_solver)
+{
+  PMG_CHECK(pc && inner && !strcmp(pc->type, "woodbury"), PMG_ERR_ARG_WRONG, "not a woodbury PC");
+  pc_woodbury *d = (pc_woodbury *)pc->data;
+  char         pre[sizeof inner->prefix + 32];
+  snprintf(pre, sizeof pre, "%s%s", pc->prefix, is_solver ? "pc_woodbury_solver_" : "pc_woodbury_sampler");
+  PMG_CALL(pmg_pc_set_options_prefix(inner, pre));
+  pmg_pc *slot = is_solver ? &d->solver : &d->sampler;
+  if (*slot && *slot != inner) pmg_pc_destroy(slot);
+  *slot           = inner;
+  pc->setupcalled = 0;
+  return PMG_SUCCESS;
+}
+pmg_status pmg_pc_woodbury_set_solver(pmg_pc pc, pmg_pc solver) { return woodbury_adopt(pc, solver, 1); }
+pmg_status pmg_pc_woodbury_set_sampler(pmg_pc pc, pmg_pc sampler) { return woodbury_adopt(pc, sampler, 0); }
+
+static pmg_status woodbury_set_inner_type(pmg_pc pc, const char *type, int is_solver) /* :215-243 */
+{
+  pmg_pc inner = NULL;
+  PMG_CALL(pmg_pc_create(&inner));
+  pmg_status st = woodbury_adopt(pc, inner, is_solver);
+  if (st) {
+    pmg_pc_destroy(&inner);
+    return st;
+  }
+  return pmg_pc_set_type(inner, type);
+}
+static pmg_status woodbury_setfromoptions(pmg_pc pc) /* PCSetFromOptions_Woodbury :245-261 */
+{
+  pc_woodbury *d = (pc_woodbury *)pc->data;
+  const char  *v;
+  if ((v = opt_find(pc->prefix, "-pc_woodbury_solver"))) PMG_CALL(woodbury_set_inner_type(pc, v, 1));
+  if ((v = opt_find(pc->prefix, "-pc_woodbury_sampler"))) PMG_CALL(woodbury_set_inner_type(pc, v, 0));
+  if (d->solver && d->solver->ops.setfromoptions) PMG_CALL(d->solver->ops.setfromoptions(d->solver));
+  if (d->sampler && d->sampler->ops.setfromoptions) PMG_CALL(d->sampler->ops.setfromoptions(d->sampler));
+  pc->setupcalled = 0;
+  return PMG_SUCCESS;
+}
+
+static pmg_status woodbury_setup(pmg_pc pc) /* PCSetUp_Woodbury :142-183 + PCWoodburyBuildLRCCorrection :21-91 */
+{
+  pc_woodbury *d = (pc_woodbury *)pc->data;
+  PMG_CHECK(d->solver && d->sampler, PMG_ERR_SUP, "Must provide sampler and solver");          /* :151 */
+  PMG_CHECK(pc->pmat->lrc_k, PMG_ERR_SUP, "PCWoodbury only supports matrices of type LRC");    /* :161 */
+  woodbury_free_setup(d);
+  const int32_t n = pc->pmat->n, k = pc->pmat->lrc_k;
+  d->k     = k;
+  d->Abase = (pmg_mat)malloc(sizeof *d->Abase);
+  PMG_CHECK(d->Abase, PMG_ERR_MEM, "out of host memory");
+  *d->Abase       = *pc->pmat; /* MatLRCGetMats(pc->pmat, &A, &B, &S, NULL), :162 */
+  d->Abase->lrc_k = 0;
+  d->Abase->lrc_B = d->Abase->lrc_S = NULL;
+  double sq[64];
+  for (int c = 0; c < k; ++c) sq[c] = sqrt(fabs(pc->pmat->lrc_S[c])); /* VecSqrtAbs, :177 */
+  PMG_CALL(pmg_dev_upload((void **)&d->B, pc->pmat->lrc_B, sizeof(double) * (size_t)n * k));
+  PMG_CALL(pmg_dev_upload((void **)&d->S_sqrt, sq, sizeof(double) * (size_t)k));
+  PMG_CALL(pmg_dev_alloc((void **)&d->G, sizeof(double) * (size_t)n * k));
+  PMG_CALL(pmg_dev_alloc((void **)&d->wk, sizeof(double) * 64));
+  PMG_CALL(pmg_dev_alloc((void **)&d->partial, sizeof(double) * (size_t)pmgk_lrc_nblocks(n) * k));
+  PMG_CALL(pmg_dev_alloc((void **)&d->w, sizeof(double) * (size_t)n));
+  PMG_CALL(pmg_pc_set_operators(d->solver, d->Abase)); /* :178-181 */
+  PMG_CALL(pmg_pc_set_operators(d->sampler, d->Abase));
+  PMG_CALL(pmg_pc_setup(d->solver));
+  PMG_CALL(pmg_pc_setup(d->sampler));
+  PMG_CHECK(d->sampler->ops.applyrichardson, PMG_ERR_SUP, "PC type %s does not have applyrichardson", d->sampler->type);
+  /* G = C (S^-1 + B^T C)^-1 with C = solver(B) column by column from a zero guess (:35-50, :52-81) */
+  double    *Cm = NULL, *Sb_dev = NULL;
+  double    *T = (double *)malloc(sizeof(double) * (size_t)k * k), *Sb = (double *)malloc(sizeof(double) * (size_t)k * k);
+  pmg_status st = (T && Sb) ? PMG_SUCCESS : pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+  if (!st) st = pmg_dev_alloc((void **)&Cm, sizeof(double) * (size_t)n * k);
+  if (!st) st = pmg_dev_alloc((void **)&Sb_dev, sizeof(double) * (size_t)k * k);
+  for (int c = 0; c < k && !st; ++c) {
+    if (hipMemsetAsync(Cm + (size_t)n * c, 0, sizeof(double) * (size_t)n, NULL) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+    if (!st) st = pmg_pc_apply(d->solver, d->B + (size_t)n * c, Cm + (size_t)n * c, NULL); /* PCApply(wb->solver, b, x), :45 */
+  }
+  for (int c = 0; c < k && !st; ++c) { /* tmp = B^T C, :53 */
+    if (pmgk_lrc_btx(n, k, d->B, n, Cm + (size_t)n * c, d->partial, NULL, d->wk, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
+    if (!st && hipMemcpy(T + (size_t)k * c, d->wk, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
+  }
+  if (!st) {
+    for (int c = 0; c < k; ++c) T[c + (size_t)k * c] += 1.0 / pc->pmat->lrc_S[c]; /* + S^-1, :66-68 */
+    if (pmg_invert_small(k, T, Sb)) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "S^-1 + B^T M^-1 B is singular");
+  }
+  if (!st && hipMemcpy(Sb_dev, Sb, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "upload failed");
+  if (!st && pmgk_lrc_gemm_small(n, k, Cm, n, Sb_dev, d->G, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed"); /* G = C Sb, :78 */
+  if (!st && hipDeviceSynchronize() != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device error while building the Woodbury correction");
+  free(T);
+  free(Sb);
+  pmg_dev_free(Cm);
+  pmg_dev_free(Sb_dev);
+  if (st) return st;
+  pmg_pc_destroy(&d->solver); /* :182 */
+  return PMG_SUCCESS;
+}
+
+static pmg_status woodbury_applyrichardson(pmg_pc pc, const double *b, double *y, int32_t its, int guesszero, int32_t *outits, void *stream)
+{ /* PCApplyRichardson_Woodbury :263-289 */
+  (void)guesszero;
+  pc_woodbury  *d = (pc_woodbury *)pc->data;
+  const int32_t n = pc->pmat->n, k = d->k;
+  for (int32_t it = 0; it < its; ++it) {
+    PMG_KERNEL(pmgk_fill_normal_rows(k, pc_seed(pc), pc->counter++, d->wk, stream));      /* VecSetRandomStandardNormal(wb->wk), :275 */
+    PMG_KERNEL(pmgk_lrc_mul(k, d->wk, d->S_sqrt, d->wk, stream));                         /* VecPointwiseMult, :276              */
+    PMG_KERNEL(pmgk_lrc_axpy_cols(n, k, d->B, n, d->wk, 1.0, b, d->w, stream));           /* MatMultAdd(B, wk, b, w), :277       */
+    int32_t done = 0;
+    PMG_CALL(d->sampler->ops.applyrichardson(d->sampler, d->w, y, 1, 0, &done, stream)); /* one sample of the A-sampler, :278    */
+    PMG_KERNEL(pmgk_lrc_btx(n, k, d->B, n, y, d->partial, NULL, d->wk, stream));          /* wk = B^T y, :280                   */
+    PMG_KERNEL(pmgk_lrc_axpy_cols(n, k, d->G, n, d->wk, -1.0, y, y, stream));             /* y -= G wk, :281-282                */
+    PMG_CALL(pc_notify(pc, it, y, stream));
+  }
+  *outits = its;
+  return PMG_SUCCESS;
+}
+
+static pmg_status PCCreate_Woodbury(pmg_pc pc) /* :291-302 */
+{
+  pc_woodbury *d = (pc_woodbury *)calloc(1, sizeof *d);
+  PMG_CHECK(d, PMG_ERR_MEM, "out of host memory");
+  pc->data                = d;
+  pc->ops.setup           = woodbury_setup;
+  pc->ops.reset           = woodbury_reset;
+  pc->ops.destroy         = woodbury_destroy;
+  pc->ops.setfromoptions  = woodbury_setfromoptions;
+  pc->ops.applyrichardson = woodbury_applyrichardson;
+  return PMG_SUCCESS;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
 /* ParMGMCInitialize / ParMGMCFinalize (src/parmgmc.c:118-137)                                           */
 /* ---------------------------------------------------------------------------------------------------- */
 pmg_status pmg_initialize(void)
@@ -825,6 +1000,7 @@ pmg_status pmg_initialize(void)
   PMG_CALL(pmg_pc_register("gamgmc", PCCreate_GAMGMC));
   PMG_CALL(pmg_pc_register("cholsampler", PCCreate_CholSampler));
   PMG_CALL(pmg_pc_register("parsor", PCCreate_PARSOR));
+  PMG_CALL(pmg_pc_register("woodbury", PCCreate_Woodbury));
   PMG_CALL(pmg_pc_register("shell", PCCreate_Shell));
   return PMG_SUCCESS;
 }

@@ -137,10 +137,25 @@ class PC:
     def set_noise_counter(self, counter: int):
         check(lib.pmg_pc_set_noise_counter(self._h, counter))
 
+    def woodbury_set_solver(self, solver: "PC"):
+        """PCWoodburySetSolver (reference src/woodbury.c:185-198); the woodbury PC takes the inner PC over."""
+        check(lib.pmg_pc_woodbury_set_solver(self._h, solver._h))
+        solver._borrowed = True
+        self._inner = getattr(self, "_inner", []) + [solver]
+
+    def woodbury_set_sampler(self, sampler: "PC"):
+        """PCWoodburySetSampler (reference src/woodbury.c:200-213)."""
+        check(lib.pmg_pc_woodbury_set_sampler(self._h, sampler._h))
+        sampler._borrowed = True
+        self._inner = getattr(self, "_inner", []) + [sampler]
+
     def reset(self):
         check(lib.pmg_pc_reset(self._h))
 
     def destroy(self):
+        if getattr(self, "_borrowed", False):  # owned by a woodbury PC
+            self._h = C.c_void_p()
+            return
         if self._h:
             check(lib.pmg_pc_destroy(C.byref(self._h)))
 
