@@ -6,7 +6,11 @@
 // row (324 B/row in the sliced-ELL form): a sweep moves ~24 B per unknown like the fine level.  Replaces, for these
 // levels, MCSORApply_SEQAIJ (reference src/mc_sor.c:241-296) + PrepareRHS (src/pc_mcgibbs.c:119-128) and PCMG's
 // residual / MatRestrict / MatInterpolateAdd (PETSc, entered at reference src/pc_gamgmc.c:246,255).
-// Vectors are in natural order (i fastest); colours are the 8 parities (i&1, j&1, k&1) -- red-black is not a valid
+// Vectors hold the owned planes kz0 .. kz0+nz-1 of the nzg global planes in natural order (i fastest) between one
+// ghost plane below and one above (element (i, j, k) at i + nx (j + ny (k - kz0 + 1))); on a single device kz0 = 0,
+// nz = nzg and the ghost planes are never read, on a z-slab they hold the neighbouring device's boundary planes.
+// Position classes, parities and noise counters use GLOBAL indices, so a slab run is bit-identical to the
+// single-device run.  Colours are the 8 parities (i&1, j&1, k&1) -- red-black is not a valid
 // colouring of a 27-point stencil -- swept in the order of their compressed index, one launch per colour.  The sum
 // runs over the neighbours in ascending natural index with the diagonal skipped, i.e. in CSR storage order, absent
 // neighbours contributing an exact +0, and the noise is the row stream of the natural index, so results are
@@ -20,7 +24,7 @@ namespace {
 __device__ __forceinline__ int pos_class(int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 2 : 1); }
 
 template <bool NOISY>
-__global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int px, int py, int pz, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, double *y)
+__global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int px, int py, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, double *y)
 {
   __shared__ double           s_coef[27 * 27], s_idiag[27], s_sqrtd[27];
   __shared__ pmg::LogTabEntry s_logtab[NOISY ? PMG_LOGTAB_SIZE : 1];
@@ -33,12 +37,13 @@ __global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int 
   if (NOISY) pmg::load_log_table(s_logtab);
   __syncthreads();
   const int ii = blockIdx.x * 256 + tid; // index within the colour along x
-  const int i = 2 * ii + px, j = 2 * (int)blockIdx.y + py, k = 2 * (int)blockIdx.z + pz;
-  if (i >= S.nx || j >= S.ny || k >= S.nz) return;
-  const int64_t row = i + (int64_t)S.nx * (j + (int64_t)S.ny * k);
-  const int     cls = pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nz);
-  const double *cf  = s_coef + 27 * cls;
-  double        sum = b[row];
+  const int i = 2 * ii + px, j = 2 * (int)blockIdx.y + py, k = 2 * (int)blockIdx.z + kfirst; // k: global plane
+  if (i >= S.nx || j >= S.ny || k >= S.kz0 + S.nz) return;
+  const int64_t row  = i + (int64_t)S.nx * (j + (int64_t)S.ny * k); // global natural index: the noise counter
+  const int64_t lrow = i + (int64_t)S.nx * (j + (int64_t)S.ny * (k - S.kz0 + 1));
+  const int     cls  = pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nzg);
+  const double *cf   = s_coef + 27 * cls;
+  double        sum  = b[lrow];
   if (NOISY) {
     double z0, z1;
     pmg::normal_pair((uint32_t)((uint64_t)row >> 1), 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int 
   int e = 0;
   for (int dz = -1; dz <= 1; ++dz) {
     const int  kk  = k + dz;
-    const bool okz = kk >= 0 && kk < S.nz;
+    const bool okz = kk >= 0 && kk < S.nzg;
     for (int dy = -1; dy <= 1; ++dy) {
       const int  jj  = j + dy;
       const bool oky = okz && jj >= 0 && jj < S.ny;
@@ -55,11 +60,11 @@ __global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int 
         if (e == 13) continue; // the diagonal
         const int  i2 = i + dx;
         const bool ok = oky && i2 >= 0 && i2 < S.nx;
-        if (ok) sum = sum - cf[e] * y[i2 + (int64_t)S.nx * (jj + (int64_t)S.ny * kk)]; // CSR rows hold in-domain entries only
+        if (ok) sum = sum - cf[e] * y[i2 + (int64_t)S.nx * (jj + (int64_t)S.ny * (kk - S.kz0 + 1))]; // CSR rows hold in-domain entries only
       }
     }
   }
-  y[row] = one_minus_omega * y[row] + s_idiag[cls] * sum;
+  y[lrow] = one_minus_omega * y[lrow] + s_idiag[cls] * sum;
 }
 
 // r = b - A y; the diagonal term is added last, like sell_residual_kernel
@@ -68,10 +73,10 @@ __global__ __launch_bounds__(256) void st27_residual_kernel(pmgk_st27 S, const d
   __shared__ double s_coef[27 * 27];
   for (int q = threadIdx.x; q < 27 * 27; q += 256) s_coef[q] = S.coef[q];
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = S.kz0 + blockIdx.z; // k: global plane
   if (i >= S.nx) return;
-  const int64_t row = i + (int64_t)S.nx * (j + (int64_t)S.ny * k);
-  const double *cf  = s_coef + 27 * (pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nz));
+  const int64_t row = i + (int64_t)S.nx * (j + (int64_t)S.ny * (k - S.kz0 + 1));
+  const double *cf  = s_coef + 27 * (pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nzg));
   double        sum = 0.0;
   int           e   = 0;
   for (int dz = -1; dz <= 1; ++dz)
@@ -79,50 +84,54 @@ __global__ __launch_bounds__(256) void st27_residual_kernel(pmgk_st27 S, const d
       for (int dx = -1; dx <= 1; ++dx, ++e) {
         if (e == 13) continue;
         const int i2 = i + dx, jj = j + dy, kk = k + dz;
-        if (i2 >= 0 && i2 < S.nx && jj >= 0 && jj < S.ny && kk >= 0 && kk < S.nz) sum = sum + cf[e] * y[i2 + (int64_t)S.nx * (jj + (int64_t)S.ny * kk)];
+        if (i2 >= 0 && i2 < S.nx && jj >= 0 && jj < S.ny && kk >= 0 && kk < S.nzg) sum = sum + cf[e] * y[i2 + (int64_t)S.nx * (jj + (int64_t)S.ny * (kk - S.kz0 + 1))];
       }
   sum    = sum + cf[13] * y[row];
   r[row] = b[row] - sum;
 }
 
-// natural-order Q1 restriction b_c = P^T r (fine nfx x nfy x nfz -> coarse S dims) and prolongation x += P e_c
-__global__ __launch_bounds__(256) void st27_restrict_kernel(int nfx, int nfy, int nfz, int ncx, int ncy, int ncz, const double *__restrict__ r, double *__restrict__ bc)
+// Q1 restriction b_c = P^T r and prolongation x += P e_c between two such levels.  F / C give the fine and coarse
+// extents: n* global sizes, kz0 / nz the owned planes; a coarse plane K is owned by the device that owns fine plane
+// 2K, its restriction reads the fine planes 2K-1 .. 2K+1 (the outer ones may be ghost planes of r).
+__global__ __launch_bounds__(256) void st27_restrict_kernel(pmgk_st27_dims F, pmgk_st27_dims C, const double *__restrict__ r, double *__restrict__ bc)
 {
-  const int I = blockIdx.x * 256 + threadIdx.x, J = blockIdx.y, K = blockIdx.z;
-  if (I >= ncx) return;
-  const int rx = nfx != ncx, ry = nfy != ncy, rz = nfz != ncz;
+  const int I = blockIdx.x * 256 + threadIdx.x, J = blockIdx.y, K = C.kz0 + blockIdx.z;
+  if (I >= C.nx) return;
+  const int rx = F.nx != C.nx, ry = F.ny != C.ny, rz = F.nzg != C.nzg;
   const int fi = rx ? 2 * I : I, fj = ry ? 2 * J : J, fk = rz ? 2 * K : K;
   double    s  = 0.0;
   for (int dz = rz ? -1 : 0; dz <= (rz ? 1 : 0); ++dz) {
     const int k = fk + dz;
-    if (k < 0 || k >= nfz) continue;
+    if (k < 0 || k >= F.nzg) continue;
     for (int dy = ry ? -1 : 0; dy <= (ry ? 1 : 0); ++dy) {
       const int j = fj + dy;
-      if (j < 0 || j >= nfy) continue;
+      if (j < 0 || j >= F.ny) continue;
       for (int dx = rx ? -1 : 0; dx <= (rx ? 1 : 0); ++dx) {
         const int i = fi + dx;
-        if (i < 0 || i >= nfx) continue;
+        if (i < 0 || i >= F.nx) continue;
         const double w = (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0);
-        s              = s + w * r[i + (int64_t)nfx * (j + (int64_t)nfy * k)];
+        s              = s + w * r[i + (int64_t)F.nx * (j + (int64_t)F.ny * (k - F.kz0 + 1))];
       }
     }
   }
-  bc[I + (int64_t)ncx * (J + (int64_t)ncy * K)] = s;
+  bc[I + (int64_t)C.nx * (J + (int64_t)C.ny * (K - C.kz0 + 1))] = s;
 }
 
-__global__ __launch_bounds__(256) void st27_prolong_add_kernel(int nfx, int nfy, int nfz, int ncx, int ncy, int ncz, const double *__restrict__ ec, double *__restrict__ x)
+// fine planes kbegin .. kbegin+gridDim.z-1 (global): the owned ones and, on a slab, the in-domain ghost planes, whose
+// interpolated values every device can form from its own coarse planes + coarse ghost planes
+__global__ __launch_bounds__(256) void st27_prolong_add_kernel(pmgk_st27_dims F, pmgk_st27_dims C, int kbegin, const double *__restrict__ ec, double *__restrict__ x)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-  if (i >= nfx) return;
-  const int    rx = nfx != ncx, ry = nfy != ncy, rz = nfz != ncz;
+  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = kbegin + blockIdx.z;
+  if (i >= F.nx) return;
+  const int    rx = F.nx != C.nx, ry = F.ny != C.ny, rz = F.nzg != C.nzg;
   const int    I0 = rx ? i >> 1 : i, J0 = ry ? j >> 1 : j, K0 = rz ? k >> 1 : k;
   const int    mx = (rx && (i & 1)) ? 2 : 1, my = (ry && (j & 1)) ? 2 : 1, mz = (rz && (k & 1)) ? 2 : 1;
   const double w  = (mx == 2 ? 0.5 : 1.0) * (my == 2 ? 0.5 : 1.0) * (mz == 2 ? 0.5 : 1.0);
   double       s  = 0.0;
   for (int c = 0; c < mz; ++c)
     for (int bq = 0; bq < my; ++bq)
-      for (int a = 0; a < mx; ++a) s = s + w * ec[(I0 + a) + (int64_t)ncx * ((J0 + bq) + (int64_t)ncy * (K0 + c))];
-  const int64_t p = i + (int64_t)nfx * (j + (int64_t)nfy * k);
+      for (int a = 0; a < mx; ++a) s = s + w * ec[(I0 + a) + (int64_t)C.nx * ((J0 + bq) + (int64_t)C.ny * (K0 + c - C.kz0 + 1))];
+  const int64_t p = i + (int64_t)F.nx * (j + (int64_t)F.ny * (k - F.kz0 + 1));
   x[p]            = x[p] + s;
 }
 
@@ -130,36 +139,49 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
 
-// one directional sweep: the 8 (4 in 2-D) parity colours in ascending / descending compressed-colour order
-extern "C" int pmgk_st27_sweep(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream)
+// half of one directional sweep: phase 0 = the first four colours of the sweep order, phase 1 = the last four.  A
+// phase touches planes of ONE z-parity (forward: even planes first), so on a z-slab the boundary planes are exchanged
+// once per phase.
+extern "C" int pmgk_st27_sweep_phase(const pmgk_st27 *S, int backward, int phase, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream)
 {
   const double om1 = 1. - omega;
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 4 * phase; q < 4 * phase + 4; ++q) {
     const int col = backward ? 7 - q : q;
     const int px = col & 1, py = (col >> 1) & 1, pz = (col >> 2) & 1;
-    const int cx = (S->nx - px + 1) / 2, cy = (S->ny - py + 1) / 2, cz = (S->nz - pz + 1) / 2; // points of this parity
+    const int kfirst = S->kz0 + ((pz - S->kz0) & 1); // first owned plane of parity pz
+    const int cx = (S->nx - px + 1) / 2, cy = (S->ny - py + 1) / 2, cz = (S->kz0 + S->nz - kfirst + 1) / 2; // points of this parity
     if (cx <= 0 || cy <= 0 || cz <= 0) continue;
     const dim3 grid((cx + 255) / 256, cy, cz), block(256);
-    if (noisy) hipLaunchKernelGGL((st27_color_sweep_kernel<true>), grid, block, 0, (hipStream_t)stream, *S, px, py, pz, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
-    else hipLaunchKernelGGL((st27_color_sweep_kernel<false>), grid, block, 0, (hipStream_t)stream, *S, px, py, pz, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
+    if (noisy) hipLaunchKernelGGL((st27_color_sweep_kernel<true>), grid, block, 0, (hipStream_t)stream, *S, px, py, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
+    else hipLaunchKernelGGL((st27_color_sweep_kernel<false>), grid, block, 0, (hipStream_t)stream, *S, px, py, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
   }
   return launch_status();
 }
 
+// one directional sweep: the 8 (4 in 2-D) parity colours in ascending / descending compressed-colour order
+extern "C" int pmgk_st27_sweep(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream)
+{
+  if (pmgk_st27_sweep_phase(S, backward, 0, omega, noisy, seed, sweep, b, y, stream)) return 1;
+  return pmgk_st27_sweep_phase(S, backward, 1, omega, noisy, seed, sweep, b, y, stream);
+}
+
 extern "C" int pmgk_st27_residual(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream)
 {
+  if (S->nz <= 0) return 0;
   hipLaunchKernelGGL(st27_residual_kernel, dim3((S->nx + 255) / 256, S->ny, S->nz), dim3(256), 0, (hipStream_t)stream, *S, b, y, r);
   return launch_status();
 }
 
-extern "C" int pmgk_st27_restrict(int nfx, int nfy, int nfz, int ncx, int ncy, int ncz, const double *r, double *bc, void *stream)
+extern "C" int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims *C, const double *r, double *bc, void *stream)
 {
-  hipLaunchKernelGGL(st27_restrict_kernel, dim3((ncx + 255) / 256, ncy, ncz), dim3(256), 0, (hipStream_t)stream, nfx, nfy, nfz, ncx, ncy, ncz, r, bc);
+  if (C->nz <= 0) return 0;
+  hipLaunchKernelGGL(st27_restrict_kernel, dim3((C->nx + 255) / 256, C->ny, C->nz), dim3(256), 0, (hipStream_t)stream, *F, *C, r, bc);
   return launch_status();
 }
 
-extern "C" int pmgk_st27_prolong_add(int nfx, int nfy, int nfz, int ncx, int ncy, int ncz, const double *ec, double *x, void *stream)
+extern "C" int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_dims *C, int kbegin, int kcount, const double *ec, double *x, void *stream)
 {
-  hipLaunchKernelGGL(st27_prolong_add_kernel, dim3((nfx + 255) / 256, nfy, nfz), dim3(256), 0, (hipStream_t)stream, nfx, nfy, nfz, ncx, ncy, ncz, ec, x);
+  if (kcount <= 0) return 0;
+  hipLaunchKernelGGL(st27_prolong_add_kernel, dim3((F->nx + 255) / 256, F->ny, kcount), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, ec, x);
   return launch_status();
 }

@@ -19,16 +19,21 @@ __device__ __forceinline__ int64_t cvec_pos(const pmgk_grid_layout &L, int i, in
   return (int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + (i >> 1);
 }
 
-// b_c[cpos[I]] = sum over the <= 27 fine points 2I+d, d in {-1,0,1}^3 (only refined directions), of w(d) r(2I+d)
-__global__ __launch_bounds__(256) void q1_restrict_kernel(pmgk_grid_layout L, int ncx, int ncy, int ncz, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ r, double *__restrict__ bc)
+__device__ __forceinline__ int64_t coarse_pos(const pmgk_st27_dims &C, const int32_t *__restrict__ cpos, int I, int J, int K)
 {
-  const int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y, K = blockIdx.z;
-  if (I >= ncx) return;
+  return cpos ? (int64_t)cpos[I + C.nx * (J + C.ny * K)] : I + (int64_t)C.nx * (J + (int64_t)C.ny * (K - C.kz0 + 1));
+}
+
+// b_c(I) = sum over the <= 27 fine points 2I+d, d in {-1,0,1}^3 (only refined directions), of w(d) r(2I+d); K global
+__global__ __launch_bounds__(256) void q1_restrict_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ r, double *__restrict__ bc)
+{
+  const int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y, K = C.kz0 + blockIdx.z;
+  if (I >= C.nx) return;
   const int fi = rx ? 2 * I : I, fj = ry ? 2 * J : J, fk = rz ? 2 * K : K;
   double    s  = 0.0;
   for (int dz = rz ? -1 : 0; dz <= (rz ? 1 : 0); ++dz) {
-    const int k = fk + dz;
-    if (k < 0 || k >= L.nz) continue;
+    const int kg = fk + dz;
+    if (kg < 0 || kg >= L.nzg) continue;
     for (int dy = ry ? -1 : 0; dy <= (ry ? 1 : 0); ++dy) {
       const int j = fj + dy;
       if (j < 0 || j >= L.ny) continue;
@@ -36,41 +41,41 @@ __global__ __launch_bounds__(256) void q1_restrict_kernel(pmgk_grid_layout L, in
         const int i = fi + dx;
         if (i < 0 || i >= L.nx) continue;
         const double w = (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0);
-        s              = s + w * r[cvec_pos(L, i, j, k)];
+        s              = s + w * r[cvec_pos(L, i, j, kg - L.kz0)];
       }
     }
   }
-  bc[cpos[I + ncx * (J + ncy * K)]] = s;
+  bc[coarse_pos(C, cpos, I, J, K)] = s;
 }
 
 // x += P e_c on the colour-partitioned fine vector: thread = two consecutive same-colour points (one 16-byte
 // read-modify-write), blocks of 64 lanes x 4 lines like the sweep; up to 8 coarse reads per point (L2-resident),
 // summed in ascending coarse index.
-__device__ __forceinline__ double q1_interp_point(int i, int j, int k, int ncx, int ncy, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ ec)
-{
+__device__ __forceinline__ double q1_interp_point(int i, int j, int k, const pmgk_st27_dims &C, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ ec)
+{ // k: global fine plane
   const int    I0 = rx ? i >> 1 : i, J0 = ry ? j >> 1 : j, K0 = rz ? k >> 1 : k;
   const int    mx = (rx && (i & 1)) ? 2 : 1, my = (ry && (j & 1)) ? 2 : 1, mz = (rz && (k & 1)) ? 2 : 1;
   const double w  = (mx == 2 ? 0.5 : 1.0) * (my == 2 ? 0.5 : 1.0) * (mz == 2 ? 0.5 : 1.0);
   double       s  = 0.0;
   for (int c = 0; c < mz; ++c)
     for (int bq = 0; bq < my; ++bq)
-      for (int a = 0; a < mx; ++a) s = s + w * ec[cpos[(I0 + a) + ncx * ((J0 + bq) + ncy * (K0 + c))]];
+      for (int a = 0; a < mx; ++a) s = s + w * ec[coarse_pos(C, cpos, I0 + a, J0 + bq, K0 + c)];
   return s;
 }
 
 typedef double d2t __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void q1_prolong_add_kernel(pmgk_grid_layout L, int ncx, int ncy, int ncz, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ ec, double *__restrict__ x)
+__global__ __launch_bounds__(256) void q1_prolong_add_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int rx, int ry, int rz, int kbegin, const int32_t *__restrict__ cpos, const double *__restrict__ ec, double *__restrict__ x)
 {
-  const int t = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z >> 1, c = blockIdx.z & 1;
+  const int t = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = kbegin + (int)(blockIdx.z >> 1), c = blockIdx.z & 1; // k: local plane, -1 / nz = ghosts
   if (j >= L.ny || 2 * t >= L.sx) return;
   const int p  = (c + j + k + L.kz0) & 1;
   const int i0 = 4 * t + p, i1 = i0 + 2;
   if (i0 >= L.nx) return;
   double       *px = x + (int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + 2 * t;
   d2t           v  = *reinterpret_cast<d2t *>(px);
-  v.x              = v.x + q1_interp_point(i0, j, k, ncx, ncy, rx, ry, rz, cpos, ec);
-  if (i1 < L.nx) v.y = v.y + q1_interp_point(i1, j, k, ncx, ncy, rx, ry, rz, cpos, ec);
+  v.x              = v.x + q1_interp_point(i0, j, k + L.kz0, C, rx, ry, rz, cpos, ec);
+  if (i1 < L.nx) v.y = v.y + q1_interp_point(i1, j, k + L.kz0, C, rx, ry, rz, cpos, ec);
   *reinterpret_cast<d2t *>(px) = v;
 }
 
@@ -78,18 +83,20 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
 
-extern "C" int pmgk_q1_restrict(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *r_cvec, double *bc, void *stream)
+extern "C" int pmgk_q1_restrict(const pmgk_grid_layout *L, const pmgk_st27_dims *C, const int32_t *cpos, const double *r_cvec, double *bc, void *stream)
 {
-  const int  rx = ncx != L->nx, ry = ncy != L->ny, rz = ncz != L->nz;
-  const dim3 block(64), grid((ncx + 63) / 64, ncy, ncz);
-  hipLaunchKernelGGL(q1_restrict_kernel, grid, block, 0, (hipStream_t)stream, *L, ncx, ncy, ncz, rx, ry, rz, cpos, r_cvec, bc);
+  if (C->nz <= 0) return 0;
+  const int  rx = C->nx != L->nx, ry = C->ny != L->ny, rz = C->nzg != L->nzg;
+  const dim3 block(64), grid((C->nx + 63) / 64, C->ny, C->nz);
+  hipLaunchKernelGGL(q1_restrict_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, cpos, r_cvec, bc);
   return launch_status();
 }
 
-extern "C" int pmgk_q1_prolong_add(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *ec, double *x_cvec, void *stream)
+extern "C" int pmgk_q1_prolong_add(const pmgk_grid_layout *L, const pmgk_st27_dims *C, const int32_t *cpos, int kbegin, int kcount, const double *ec, double *x_cvec, void *stream)
 {
-  const int  rx = ncx != L->nx, ry = ncy != L->ny, rz = ncz != L->nz;
-  const dim3 block(64, 4), grid((L->sx / 2 + 63) / 64, (L->ny + 3) / 4, 2 * L->nz);
-  hipLaunchKernelGGL(q1_prolong_add_kernel, grid, block, 0, (hipStream_t)stream, *L, ncx, ncy, ncz, rx, ry, rz, cpos, ec, x_cvec);
+  if (kcount <= 0) return 0;
+  const int  rx = C->nx != L->nx, ry = C->ny != L->ny, rz = C->nzg != L->nzg;
+  const dim3 block(64, 4), grid((L->sx / 2 + 63) / 64, (L->ny + 3) / 4, 2 * kcount);
+  hipLaunchKernelGGL(q1_prolong_add_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, kbegin, cpos, ec, x_cvec);
   return launch_status();
 }

@@ -81,24 +81,34 @@ int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, c
 /* y[rowpos[r]] (+)= alpha * sum_k vals[k] x[colidx[k]] over the rows of a CSR block whose output positions are
    given explicitly (transfer operators between level layouts); accumulate != 0 adds to y */
 int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, void *stream);
-/* matrix-free Q1 transfers between a grid level (cvec) and the next coarser level whose layout is given by
-   cpos[natural coarse index] (device array) */
-int pmgk_q1_restrict(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *r_cvec, double *bc, void *stream);
-int pmgk_q1_prolong_add(const pmgk_grid_layout *L, int ncx, int ncy, int ncz, const int32_t *cpos, const double *ec, double *x_cvec, void *stream);
 /* dense lower Cholesky in place + W = L^-1 on the device (npad multiple of 32; MFMA f64 trailing updates) */
 int pmgk_potrf_inverse(int32_t npad, double *A_colmajor, double *W_colmajor, double *Dinv_scratch, int *info_dev, void *stream);
 int pmgk_pack_rowmajor(int32_t n, const double *in_colmajor, int64_t ld, int transpose, double *out_rowmajor, void *stream);
-/* class-stencil form of a 27-point (9-point) Galerkin operator on an nx*ny*nz grid: coef[27*cls + e], cls = position
+/* class-stencil form of a 27-point (9-point) Galerkin operator on an nx*ny*nzg grid: coef[27*cls + e], cls = position
    class (first / interior / last per direction), e = 9(dz+1) + 3(dy+1) + (dx+1); idiag = (1/d)*omega, sqrtdiag per
-   class; device arrays */
+   class; device arrays.  Vectors hold the owned planes kz0 .. kz0+nz-1 between two ghost planes:
+   element (i, j, k) at i + nx*(j + ny*(k - kz0 + 1)); single device: kz0 = 0, nz = nzg. */
 typedef struct {
   int32_t       nx, ny, nz;
+  int32_t       kz0, nzg;
   const double *coef, *idiag, *sqrtdiag;
 } pmgk_st27;
+typedef struct {
+  int32_t nx, ny, nz, kz0, nzg;
+} pmgk_st27_dims;
 int pmgk_st27_sweep(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream);
+int pmgk_st27_sweep_phase(const pmgk_st27 *S, int backward, int phase, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream);
 int pmgk_st27_residual(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream);
-int pmgk_st27_restrict(int nfx, int nfy, int nfz, int ncx, int ncy, int ncz, const double *r, double *bc, void *stream);
-int pmgk_st27_prolong_add(int nfx, int nfy, int nfz, int ncx, int ncy, int ncz, const double *ec, double *x, void *stream);
+int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims *C, const double *r, double *bc, void *stream);
+/* fine planes kbegin .. kbegin+kcount-1 (global indices; may include the in-domain ghost planes of a slab) */
+int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_dims *C, int kbegin, int kcount, const double *ec, double *x, void *stream);
+/* matrix-free Q1 transfers between a grid level (cvec, possibly a z-slab) and the next coarser level: C gives the
+   coarse extents (global nzg, owned planes kz0 .. kz0+nz-1; coarse plane K belongs to the owner of fine plane 2K).
+   cpos != NULL: coarse layout given by cpos[global natural coarse index] (single device only); cpos == NULL: the
+   plane-padded natural layout of pmgk_st27.  The restriction reads r on the ghost planes of a slab; the prolongation
+   covers the fine local planes kbegin .. kbegin+kcount-1 (-1 and nz are the ghost planes). */
+int pmgk_q1_restrict(const pmgk_grid_layout *L, const pmgk_st27_dims *C, const int32_t *cpos, const double *r_cvec, double *bc, void *stream);
+int pmgk_q1_prolong_add(const pmgk_grid_layout *L, const pmgk_st27_dims *C, const int32_t *cpos, int kbegin, int kcount, const double *ec, double *x_cvec, void *stream);
 /* triangular matrix-vector products of the coarse exact sampler (row-major n x n, lower or upper part) */
 int pmgk_tri_gemv(int32_t n, int upper, const double *M, const double *x, const double *add, double *out, void *stream);
 /* low-rank (MATLRC) pieces: M is n x k column-major with leading dimension ld, k <= 64 */

@@ -32,7 +32,11 @@ static void hcsr_free(hcsr *m)
 }
 
 typedef struct {
-  int32_t   nx, ny, nz, n;
+  int32_t   nx, ny, nz, n; /* global extents */
+  int32_t   kz0, nzl;      /* owned planes (0, nz on a single device and on replicated levels) */
+  int       padded;        /* plane-padded natural layout (class-stencil levels, Cholesky level): element (i,j,k) at off + i + nx (j + ny (k - kz0)) */
+  int64_t   off;           /* = nx*ny when padded */
+  int       distributed;   /* z-slab level of a multi-device hierarchy */
   int       is_grid;
   pmg_grid  g;
   pmg_mcsor mc;
@@ -42,7 +46,8 @@ typedef struct {
   int32_t  P_nrows, R_nrows;
   int32_t *cpos_dev; /* grid level only: layout position of every point of the next coarser level */
   /* class-stencil form of a structured Galerkin level (natural-order vectors) */
-  int       is_st27, nat_transfer; /* nat_transfer: this level and the next coarser one are both in natural order */
+  int       is_st27, nat_transfer; /* nat_transfer: this level and the next coarser one are both in padded natural order */
+  int       grid_transfer;         /* matrix-free Q1 transfers from this grid level (cpos_dev == NULL: padded natural coarse level) */
   pmgk_st27 st;
   double   *st_coef, *st_idiag, *st_sqrtd, *st_sqrtd_scaled;
   pmg_lrc   lrc; /* MATLRC update of a class-stencil level (grid / sliced-ELL levels keep theirs inside g / mc) */
@@ -269,6 +274,7 @@ pmg_status pmg_mgmc_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa
     h->lv[l].ny = d[1];
     h->lv[l].nz = d[2];
     h->lv[l].n  = d[0] * d[1] * d[2];
+    h->lv[l].nzl = d[2];
     if (l > 0)
       for (int q = 0; q < 3; ++q)
         if (d[q] > 1) {
@@ -382,6 +388,19 @@ pmg_status pmg_mgmc_set_keep_host(pmg_mgmc h, int keep)
   return PMG_SUCCESS;
 }
 
+static void level_set_padded(mg_level *Lv)
+{
+  Lv->padded = 1;
+  Lv->off    = (int64_t)Lv->nx * Lv->ny;
+  Lv->ld     = (int64_t)Lv->nx * Lv->ny * ((int64_t)Lv->nzl + 2);
+}
+
+static pmgk_st27_dims level_dims(const mg_level *Lv)
+{
+  pmgk_st27_dims d = {Lv->nx, Lv->ny, Lv->nzl, Lv->kz0, Lv->nz};
+  return d;
+}
+
 /* MATLRC fine-level operator A + B S B^T (MatCreateLRC in examples/ex4.c; PCSetUp_GAMGMC builds the hierarchy from
    the base matrix A, src/pc_gamgmc.c:282-286).  PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:157-196) then gives every
    level l the operator A_l + B_l S B_l^T with B_{l-1} = P_l^T B_l, for the level sampler AND the level residual; the
@@ -448,9 +467,9 @@ static pmg_status level_attach_lrc(pmg_mgmc h, mg_level *Lv, const double *B_nat
   if (Lv->is_st27) {
     int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)Lv->n);
     PMG_CHECK(pos, PMG_ERR_MEM, "out of host memory");
-    for (int32_t q = 0; q < Lv->n; ++q) pos[q] = q;
+    for (int32_t q = 0; q < Lv->n; ++q) pos[q] = q + Lv->off;
     st27_det_ctx ctx = {h, Lv};
-    pmg_status   st  = pmg_lrc_build(&Lv->lrc, h->lrc_k, Lv->n, Lv->n, B_nat, pos, h->lrc_S, st27_det_sweep, &ctx);
+    pmg_status   st  = pmg_lrc_build(&Lv->lrc, h->lrc_k, Lv->ld, Lv->n, B_nat, pos, h->lrc_S, st27_det_sweep, &ctx);
     free(pos);
     return st;
   }
@@ -602,8 +621,8 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
     PMG_CHECK(pos[l - 1], PMG_ERR_MEM, "out of host memory");
     pmg_status st27_status = PMG_SUCCESS;
     if ((!is_coarsest || h->coarse_type == 1) && !getenv("PMG_MG_NO_STENCIL") && st27_from_csr(Cc, &Ac, h->omega, &st27_status)) {
-      Cc->ld = Cc->n; /* natural order */
-      for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q;
+      level_set_padded(Cc);
+      for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q + (int32_t)Cc->off;
     } else if (!is_coarsest || h->coarse_type == 1) {
       PMG_CALL(st27_status);
       int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)Cc->n);
@@ -628,8 +647,8 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
       Cc->ld = ld32;
       PMG_CALL(pmg_mcsor_get_layout(Cc->mc, pos[l - 1]));
     } else {
-      Cc->ld = Cc->n;
-      for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q;
+      level_set_padded(Cc);
+      for (int32_t q = 0; q < Cc->n; ++q) pos[l - 1][q] = q + (int32_t)Cc->off;
     }
     if (h->lrc_k) { /* B_{l-1} = P_l^T B_l and the MATLRC level operator, src/pc_gamgmc.c:177-187 */
       double *Bc = NULL;
@@ -641,10 +660,10 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
     if (is_coarsest && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr_lowrank(Cc->n, Ac.rp, Ac.ci, Ac.v, h->lrc_k, Bcur, h->lrc_S, &h->chol));
     /* transfers: matrix-free Q1 kernels from the grid level and between natural-order levels, CSR products in
        layout numbering otherwise */
-    const int coarse_natural = Cc->is_st27 || (is_coarsest && h->coarse_type == 0);
     if (U->is_grid && !getenv("PMG_MG_CSR_TRANSFERS")) {
-      PMG_CALL(pmg_dev_upload((void **)&U->cpos_dev, pos[l - 1], sizeof(int32_t) * (size_t)Cc->n));
-    } else if (U->is_st27 && coarse_natural && !getenv("PMG_MG_CSR_TRANSFERS")) {
+      U->grid_transfer = 1;
+      if (!Cc->padded) PMG_CALL(pmg_dev_upload((void **)&U->cpos_dev, pos[l - 1], sizeof(int32_t) * (size_t)Cc->n));
+    } else if (U->is_st27 && Cc->padded && !getenv("PMG_MG_CSR_TRANSFERS")) {
       U->nat_transfer = 1;
     } else {
       U->P_nrows = P.nr;
@@ -773,6 +792,8 @@ static int st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_status *
   Lv->st.nx    = nx;
   Lv->st.ny    = ny;
   Lv->st.nz    = nz;
+  Lv->st.kz0   = 0;
+  Lv->st.nzg   = nz;
   Lv->st.coef  = Lv->st_coef;
   Lv->st.idiag = Lv->st_idiag;
   Lv->is_st27  = 1;
@@ -827,12 +848,14 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* PCMGSetResidual(..., As[l]), src/pc_gamgmc.c:194 */
     }
     else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
-    if (Lv->cpos_dev) { /* MatRestrict, matrix-free */
-      pmgk_grid_layout GL;
+    if (Lv->grid_transfer) { /* MatRestrict, matrix-free */
+      pmgk_grid_layout     GL;
+      const pmgk_st27_dims CD = level_dims(Cc);
       PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
-      PMG_KERNEL(pmgk_q1_restrict(&GL, Cc->nx, Cc->ny, Cc->nz, Lv->cpos_dev, Lv->r, Cc->b, stream));
+      PMG_KERNEL(pmgk_q1_restrict(&GL, &CD, Lv->cpos_dev, Lv->r, Cc->b, stream));
     } else if (Lv->nat_transfer) {
-      PMG_KERNEL(pmgk_st27_restrict(Lv->nx, Lv->ny, Lv->nz, Cc->nx, Cc->ny, Cc->nz, Lv->r, Cc->b, stream));
+      const pmgk_st27_dims FD = level_dims(Lv), CD = level_dims(Cc);
+      PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, Lv->r, Cc->b, stream));
     } else {
       PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, Lv->r, Cc->b, 0, stream)); /* MatRestrict */
     }
@@ -840,7 +863,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
   {
     mg_level *C0 = &h->lv[0];
     if (h->coarse_type == 0) {
-      PMG_CALL(pmg_chol_sample(h->chol, C0->b, C0->x, 1, level_seed(seed, 0), ctr[0], stream));
+      PMG_CALL(pmg_chol_sample(h->chol, C0->b + C0->off, C0->x + C0->off, 1, level_seed(seed, 0), ctr[0], stream));
     } else {
       PMG_HIP(hipMemsetAsync(C0->x, 0, sizeof(double) * (size_t)C0->ld, (hipStream_t)stream));
       if (C0->is_st27) PMG_CALL(st27_sample(h, C0, h->coarse_its, level_seed(seed, 0), &ctr[0], stream));
@@ -849,12 +872,14 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
   }
   for (int l = 1; l <= top; ++l) {
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
-    if (Lv->cpos_dev) { /* MatInterpolateAdd, matrix-free */
-      pmgk_grid_layout GL;
+    if (Lv->grid_transfer) { /* MatInterpolateAdd, matrix-free */
+      pmgk_grid_layout     GL;
+      const pmgk_st27_dims CD = level_dims(Cc);
       PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
-      PMG_KERNEL(pmgk_q1_prolong_add(&GL, Cc->nx, Cc->ny, Cc->nz, Lv->cpos_dev, Cc->x, Lv->x, stream));
+      PMG_KERNEL(pmgk_q1_prolong_add(&GL, &CD, Lv->cpos_dev, 0, Lv->nzl, Cc->x, Lv->x, stream));
     } else if (Lv->nat_transfer) {
-      PMG_KERNEL(pmgk_st27_prolong_add(Lv->nx, Lv->ny, Lv->nz, Cc->nx, Cc->ny, Cc->nz, Cc->x, Lv->x, stream));
+      const pmgk_st27_dims FD = level_dims(Lv), CD = level_dims(Cc);
+      PMG_KERNEL(pmgk_st27_prolong_add(&FD, &CD, Lv->kz0, Lv->nzl, Cc->x, Lv->x, stream));
     } else {
       PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, Cc->x, Lv->x, 1, stream)); /* MatInterpolateAdd */
     }
