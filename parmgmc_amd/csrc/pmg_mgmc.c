@@ -72,7 +72,13 @@ struct pmg_mgmc_s {
   /* MATLRC fine operator A + B S B^T (host copies until set-up; src/pc_gamgmc.c:157-196) */
   int32_t   lrc_k;
   double   *lrc_B, *lrc_S;
+  int       own_grid; /* the fine grid operator was created here (not handed in with a slab) */
 };
+
+typedef struct {
+  double coef[27 * 27];
+  int    have[27];
+} st27_table;
 
 #define MG_DRAWS_PER_SAMPLE 64u
 
@@ -495,6 +501,8 @@ static pmg_status upload_transfer(const hcsr *M, const int32_t *rowpos_of, const
 
 static pmg_status upload_transfer(const hcsr *M, const int32_t *rowpos_of, const int32_t *colpos_of, int32_t **rowpos, int32_t **rowptr, int32_t **col, double **val);
 static int        st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_status *st);
+static pmg_status stencil_tables_from_proxy(pmg_mgmc h, st27_table *tab, int *ok);
+static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab);
 
 static pmg_status mgmc_setup_user(pmg_mgmc h)
 {
@@ -568,10 +576,21 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
   if (h->is_setup) return PMG_SUCCESS;
   if (h->user_hier) return mgmc_setup_user(h);
   const int top = h->nlevels - 1;
+  if (!h->keep_host && !h->lrc_k && !getenv("PMG_MG_FULL_GALERKIN") && !getenv("PMG_MG_NO_STENCIL") && !getenv("PMG_MG_CSR_TRANSFERS")) {
+    /* class-stencil tables from the proxy hierarchy: no product with the full-size matrices */
+    st27_table *tab = (st27_table *)malloc(sizeof(st27_table) * (size_t)top);
+    PMG_CHECK(tab, PMG_ERR_MEM, "out of host memory");
+    int        ok = 0;
+    pmg_status st = stencil_tables_from_proxy(h, tab, &ok);
+    if (!st && ok) st = mgmc_setup_stencil(h, tab);
+    free(tab);
+    if (st || ok) return st;
+  }
   /* finest level: matrix-free grid operator */
   mg_level *F = &h->lv[top];
   F->is_grid  = 1;
   PMG_CALL(pmg_grid_create(F->nx, F->ny, F->nz, 0, F->nz, h->kappa, &F->g));
+  h->own_grid = 1;
   PMG_CALL(pmg_grid_set_omega(F->g, h->omega));
   PMG_CALL(pmg_grid_set_sweep_type(F->g, h->sweep_type));
   PMG_CALL(pmg_grid_cvec_len(F->g, &F->ld));
@@ -741,14 +760,13 @@ pmg_status pmg_mgmc_get_level_matrix(pmg_mgmc h, int32_t level, int which, int32
 /* Try to express the CSR operator of a structured level as 27 position-class stencils; returns 1 if every row equals
    its class stencil bit for bit (always the case for Galerkin operators of the constant-coefficient fine operator),
    0 otherwise (the caller keeps the sliced-ELL form). */
-static int st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_status *st)
+/* class-stencil table of a structured 27-point (9-point) matrix on an nx*ny*nz grid: coef[27*cls + e] and which
+   classes occur; returns 0 when the matrix is not of that form (a row is not the full in-domain 27-box, or two points
+   of one position class have different rows) */
+static int st27_extract(int nx, int ny, int nz, const hcsr *A, double *coef /* [27*27] */, int *have /* [27] */)
 {
-  *st = PMG_SUCCESS;
-  double coef[27 * 27], dg[27];
-  int    have[27];
-  memset(coef, 0, sizeof coef);
-  memset(have, 0, sizeof have);
-  const int nx = Lv->nx, ny = Lv->ny, nz = Lv->nz;
+  memset(coef, 0, sizeof(double) * 27 * 27);
+  memset(have, 0, sizeof(int) * 27);
   for (int32_t k = 0; k < nz; ++k)
     for (int32_t j = 0; j < ny; ++j)
       for (int32_t i = 0; i < nx; ++i) {
@@ -775,7 +793,13 @@ static int st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_status *
           return 0;
         }
       }
-  double idg[27], sq[27], sqs[27];
+  return 1;
+}
+
+/* upload a class-stencil table and make Lv a class-stencil level (owned planes kz0 .. kz0+nzl-1 of its nz) */
+static pmg_status st27_install(mg_level *Lv, const double *coef, const int *have, double omega)
+{
+  double       dg[27], idg[27], sq[27], sqs[27];
   const double sc = sqrt((2 - omega) / omega);
   for (int c = 0; c < 27; ++c) {
     dg[c] = have[c] ? coef[27 * c + 13] : 1.0;
@@ -784,20 +808,170 @@ static int st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_status *
     sq[c]          = sqrt(fabs(dg[c]));    /* src/pc_mcgibbs.c:149 */
     sqs[c]         = sq[c] * sc;
   }
-  *st = pmg_dev_upload((void **)&Lv->st_coef, coef, sizeof coef);
-  if (!*st) *st = pmg_dev_upload((void **)&Lv->st_idiag, idg, sizeof idg);
-  if (!*st) *st = pmg_dev_upload((void **)&Lv->st_sqrtd, sq, sizeof sq);
-  if (!*st) *st = pmg_dev_upload((void **)&Lv->st_sqrtd_scaled, sqs, sizeof sqs);
-  if (*st) return 0;
-  Lv->st.nx    = nx;
-  Lv->st.ny    = ny;
-  Lv->st.nz    = nz;
-  Lv->st.kz0   = 0;
-  Lv->st.nzg   = nz;
+  PMG_CALL(pmg_dev_upload((void **)&Lv->st_coef, coef, sizeof(double) * 27 * 27));
+  PMG_CALL(pmg_dev_upload((void **)&Lv->st_idiag, idg, sizeof idg));
+  PMG_CALL(pmg_dev_upload((void **)&Lv->st_sqrtd, sq, sizeof sq));
+  PMG_CALL(pmg_dev_upload((void **)&Lv->st_sqrtd_scaled, sqs, sizeof sqs));
+  Lv->st.nx    = Lv->nx;
+  Lv->st.ny    = Lv->ny;
+  Lv->st.nz    = Lv->nzl;
+  Lv->st.kz0   = Lv->kz0;
+  Lv->st.nzg   = Lv->nz;
   Lv->st.coef  = Lv->st_coef;
   Lv->st.idiag = Lv->st_idiag;
   Lv->is_st27  = 1;
-  return 1;
+  return PMG_SUCCESS;
+}
+
+static int st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_status *st)
+{
+  double coef[27 * 27];
+  int    have[27];
+  *st = PMG_SUCCESS;
+  if (!st27_extract(Lv->nx, Lv->ny, Lv->nz, A, coef, have)) return 0;
+  *st = st27_install(Lv, coef, have, omega);
+  return *st == PMG_SUCCESS;
+}
+
+/* ---- hierarchy from class-stencil tables ----------------------------------------------------------------------
+   The Galerkin operators of the constant-coefficient grid operator are class stencils whose 27 x 27 tables do not
+   depend on the grid size, so they are computed on a small PROXY hierarchy with the same coefficients (same kappa,
+   same h2 = 1/(nx-1)^2 of the true grid, as many levels, 2^levels + 1 points per refined direction at most): the
+   Galerkin products of the true 10^7..10^8-row matrices never have to be formed, and a z-slab of a multi-device run
+   needs nothing but its own planes.  Bit-identical to the tables extracted from the full products (the same entries
+   are summed in the same order for every point of a class; tests compare both set-ups). */
+static pmg_status stencil_tables_from_proxy(pmg_mgmc h, st27_table *tab /* [nlevels-1], level l < top */, int *ok)
+{
+  const int top = h->nlevels - 1;
+  *ok           = 0;
+  int32_t pd[64][3];
+  for (int q = 0; q < 3; ++q) {
+    const int32_t tn = q == 0 ? h->lv[top].nx : (q == 1 ? h->lv[top].ny : h->lv[top].nz);
+    const int64_t cap = ((int64_t)1 << (h->nlevels < 20 ? h->nlevels : 20)) + 1;
+    pd[top][q]        = tn == 1 ? 1 : (int32_t)(tn < cap ? tn : cap);
+  }
+  for (int l = top; l >= 1; --l)
+    for (int q = 0; q < 3; ++q) {
+      const int32_t tf = q == 0 ? h->lv[l].nx : (q == 1 ? h->lv[l].ny : h->lv[l].nz), tc = q == 0 ? h->lv[l - 1].nx : (q == 1 ? h->lv[l - 1].ny : h->lv[l - 1].nz);
+      pd[l - 1][q]     = tf == tc ? pd[l][q] : (pd[l][q] - 1) / 2 + 1; /* coarsened in the true hierarchy <=> coarsened here */
+    }
+  for (int l = top; l >= 0; --l) /* every position class of the true level must exist on the proxy level */
+    for (int q = 0; q < 3; ++q) {
+      const int32_t tn = q == 0 ? h->lv[l].nx : (q == 1 ? h->lv[l].ny : h->lv[l].nz);
+      if (pd[l][q] != tn && pd[l][q] < 3) return PMG_SUCCESS;
+    }
+  const mg_level *F = &h->lv[top];
+  rowsrc          src;
+  memset(&src, 0, sizeof src);
+  src.nx    = pd[top][0];
+  src.ny    = pd[top][1];
+  src.nz    = pd[top][2];
+  src.kappa = h->kappa;
+  src.h2    = 1. / ((F->nx - 1) * (F->nx - 1)); /* src/problems.c:24, the TRUE grid's spacing */
+  for (int nn = 0; nn < 8; ++nn) {
+    double dgl = h->kappa * h->kappa;
+    for (int q = 0; q < nn; ++q) dgl += src.h2;
+    src.diag[nn] = dgl;
+  }
+  hcsr Aprev;
+  memset(&Aprev, 0, sizeof Aprev);
+  int good = 1;
+  for (int l = top; l >= 1 && good; --l) {
+    hcsr P, R, Ac;
+    memset(&P, 0, sizeof P);
+    memset(&R, 0, sizeof R);
+    memset(&Ac, 0, sizeof Ac);
+    PMG_CALL(q1_interp(pd[l], pd[l - 1], &P));
+    PMG_CALL(hcsr_transpose(&P, &R));
+    rowsrc sl = src;
+    if (l < top) sl.A = &Aprev;
+    PMG_CALL(galerkin_rap(&sl, l == top ? 7 : 64, &P, &R, &Ac));
+    good = st27_extract(pd[l - 1][0], pd[l - 1][1], pd[l - 1][2], &Ac, tab[l - 1].coef, tab[l - 1].have);
+    hcsr_free(&P);
+    hcsr_free(&R);
+    hcsr_free(&Aprev);
+    Aprev = Ac;
+  }
+  hcsr_free(&Aprev);
+  *ok = good;
+  return PMG_SUCCESS;
+}
+
+/* assembled CSR of a class-stencil operator on the full nx*ny*nz grid (for the dense coarse factorisation) */
+static pmg_status st27_to_csr(int nx, int ny, int nz, const st27_table *t, hcsr *A)
+{
+  const int32_t n = nx * ny * nz;
+  memset(A, 0, sizeof *A);
+  A->nr = A->nc = n;
+  A->rp         = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+  A->ci         = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 27);
+  A->v          = (double *)malloc(sizeof(double) * (size_t)n * 27);
+  PMG_CHECK(A->rp && A->ci && A->v, PMG_ERR_MEM, "out of host memory");
+  int32_t nnz = 0;
+  for (int32_t k = 0; k < nz; ++k)
+    for (int32_t j = 0; j < ny; ++j)
+      for (int32_t i = 0; i < nx; ++i) {
+        const int32_t row = i + nx * (j + ny * k);
+        const int     cls = (i == 0 ? 0 : (i == nx - 1 ? 2 : 1)) + 3 * (j == 0 ? 0 : (j == ny - 1 ? 2 : 1)) + 9 * (k == 0 ? 0 : (k == nz - 1 ? 2 : 1));
+        A->rp[row]        = nnz;
+        int e             = 0;
+        for (int dz = -1; dz <= 1; ++dz)
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx, ++e)
+              if (i + dx >= 0 && i + dx < nx && j + dy >= 0 && j + dy < ny && k + dz >= 0 && k + dz < nz) {
+                A->ci[nnz]  = row + dx + nx * (dy + ny * dz);
+                A->v[nnz++] = t->coef[27 * cls + e];
+              }
+      }
+  A->rp[n] = nnz;
+  return PMG_SUCCESS;
+}
+
+/* set-up from class-stencil tables: every level below the grid level is a class-stencil level in padded natural
+   order, transfers are the matrix-free Q1 kernels, the coarsest level is factored from the expanded table */
+static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
+{
+  const int top = h->nlevels - 1;
+  mg_level *F   = &h->lv[top];
+  F->is_grid    = 1;
+  if (!F->g) {
+    PMG_CALL(pmg_grid_create(F->nx, F->ny, F->nz, 0, F->nz, h->kappa, &F->g));
+    h->own_grid = 1;
+  }
+  PMG_CALL(pmg_grid_set_omega(F->g, h->omega));
+  PMG_CALL(pmg_grid_set_sweep_type(F->g, h->sweep_type));
+  PMG_CALL(pmg_grid_cvec_len(F->g, &F->ld));
+  F->grid_transfer = 1;
+  for (int l = top - 1; l >= 0; --l) {
+    mg_level *Lv = &h->lv[l];
+    level_set_padded(Lv);
+    if (l > 0 || h->coarse_type == 1) PMG_CALL(st27_install(Lv, tab[l].coef, tab[l].have, h->omega));
+    if (l > 0) Lv->nat_transfer = 1;
+  }
+  if (h->coarse_type == 0) {
+    mg_level *C0 = &h->lv[0];
+    hcsr      A0;
+    PMG_CHECK(!C0->distributed, PMG_ERR_SUP, "the Cholesky level must not be distributed");
+    PMG_CALL(st27_to_csr(C0->nx, C0->ny, C0->nz, &tab[0], &A0));
+    pmg_status st = pmg_chol_create_csr(C0->n, A0.rp, A0.ci, A0.v, &h->chol);
+    hcsr_free(&A0);
+    PMG_CALL(st);
+  }
+  for (int l = 0; l <= top; ++l) {
+    mg_level *Lv = &h->lv[l];
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->b, sizeof(double) * (size_t)Lv->ld));
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->x, sizeof(double) * (size_t)Lv->ld));
+    PMG_CALL(pmg_dev_alloc((void **)&Lv->r, sizeof(double) * (size_t)Lv->ld));
+    PMG_HIP(hipMemset(Lv->b, 0, sizeof(double) * (size_t)Lv->ld));
+    PMG_HIP(hipMemset(Lv->x, 0, sizeof(double) * (size_t)Lv->ld));
+    PMG_HIP(hipMemset(Lv->r, 0, sizeof(double) * (size_t)Lv->ld));
+  }
+  PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)F->ld));
+  PMG_CALL(pmg_dev_alloc((void **)&h->b_lay, sizeof(double) * (size_t)F->ld));
+  PMG_HIP(hipMemset(h->y_lay, 0, sizeof(double) * (size_t)F->ld));
+  PMG_HIP(hipMemset(h->b_lay, 0, sizeof(double) * (size_t)F->ld));
+  h->is_setup = 1;
+  return PMG_SUCCESS;
 }
 
 /* `its` samples of the level sampler on a class-stencil level (same draw numbering as pmg_mcsor_sample_layout) */
@@ -946,7 +1120,7 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
   pmg_mgmc h = *hp;
   for (int l = 0; l < h->nlevels; ++l) {
     mg_level *Lv = &h->lv[l];
-    pmg_grid_destroy(&Lv->g);
+    if (h->own_grid || !Lv->is_grid) pmg_grid_destroy(&Lv->g);
     pmg_mcsor_destroy(&Lv->mc);
     pmg_dev_free(Lv->b);
     pmg_dev_free(Lv->x);

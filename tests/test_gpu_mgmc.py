@@ -268,3 +268,26 @@ def test_unstructured_hierarchy_lshape():
     # standardised errors: mean square = integrated autocorrelation time of the chain (about 4 with this plain,
     # unsmoothed aggregation; a single-level Gibbs chain on this matrix has IACT in the hundreds)
     assert np.abs(z).max() < 6.0 * np.sqrt(np.mean(z ** 2)) and 0.3 < np.mean(z ** 2) < 10.0
+
+
+@pytest.mark.parametrize("grid,levels,coarse", [((33, 17, 17), 3, "cholsampler"), ((65, 33, 1), 4, "gibbs"), ((17, 17, 17), 4, "cholsampler")])
+def test_proxy_stencil_setup_is_bit_identical_to_full_galerkin(grid, levels, coarse, monkeypatch):
+    """The default set-up takes the coarse class-stencil tables from a small proxy hierarchy (2^levels + 1 points per
+    direction) instead of forming P^T A P of the full-size matrices; the chain must not change by a bit."""
+    from parmgmc_amd import MGMC
+
+    rng = np.random.default_rng(5)
+    n = int(np.prod(grid))
+    b, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    out = []
+    for full in (False, True):
+        if full:
+            monkeypatch.setenv("PMG_MG_FULL_GALERKIN", "1")
+        mg = MGMC(*grid, 1.5, levels)
+        mg.set_smoother(True, 1.1, O.SOR_SYMMETRIC, 1)
+        mg.set_coarse(coarse, 2)
+        mg.setup()
+        yd = dev(y0)
+        mg.sample(dev(b), yd, 3, seed=17, counter0=1)
+        out.append(host(yd).copy())
+    assert np.array_equal(out[0], out[1])
