@@ -199,6 +199,15 @@ pmg_status pmg_dist_ipc_connect_loopback(pmg_dist d);
    chain is bit-identical for every number of ranks.  Work is enqueued on `stream` and an internal comm stream;
    `stream` is made to wait for the last exchange before the call returns. */
 pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b_cvec, double *y_cvec, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+/* Building blocks of the distributed V-cycle on the same transports.  pmg_dist_exchange: one round trip with both
+   z-neighbours on `stream`, nseg (<= 4) contiguous device segments per side; what is sent to the low neighbour
+   arrives in its high receive segments and vice versa (segment sizes of a pair must agree; sides without a neighbour
+   are skipped).  pmg_dist_allgather: block r (counts[r] doubles at buf + offsets[r]) is owned by rank r; afterwards
+   every rank holds all blocks.  Collective: every rank makes the same sequence of calls. */
+pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo, const int64_t *nsend_lo, double *const *recv_lo, const int64_t *nrecv_lo, const double *const *send_hi, const int64_t *nsend_hi, double *const *recv_hi, const int64_t *nrecv_hi, void *stream);
+pmg_status pmg_dist_allgather(pmg_dist d, double *buf_dev, const int64_t *offsets, const int64_t *counts, void *stream);
+/* rank / number of ranks / largest message (doubles) the generic exchange can carry */
+pmg_status pmg_dist_get_info(pmg_dist d, int32_t *rank, int32_t *nranks, int64_t *capacity);
 pmg_status pmg_dist_destroy(pmg_dist *d);
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -233,6 +242,15 @@ typedef int (*pmg_sample_callback)(int32_t it, const double *y_nat_dev, int32_t 
    odd).  Defaults = the options PCGAMGMC injects (src/pc_gamgmc.c:299-350): level sampler sorgibbs, 1 sweep
    before and after, coarse cholsampler, Galerkin coarse operators. */
 pmg_status pmg_mgmc_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa, int32_t levels, pmg_mgmc *mg);
+/* The same sampler on z-slabs of the DMDA, one rank per device (the reference distributes every PCMG level over the
+   MPI ranks; GAMG reduces coarse grids to rank 0, src/pc_chols.c:38-47,272-282).  `g` = this rank's slab of the fine
+   operator (pmg_grid_create with kz0 = cuts[rank], nz = cuts[rank+1] - cuts[rank]), `dist` = the halo transport
+   created on it (both borrowed), cuts[0..nranks] = first fine plane of every rank.  Coarse plane K belongs to the
+   owner of fine plane 2K; levels with <= 2^19 unknowns (env PMG_MG_REPLICATE_BELOW) or fewer planes than ranks are
+   replicated on every rank after one all-gather of their right-hand side.  pmg_mgmc_sample then takes this rank's
+   planes of b and y (nx*ny*nz_owned values, natural order) and is collective; samples are bit-identical for any
+   number of ranks.  Low-rank updates and host copies are single-device features. */
+pmg_status pmg_mgmc_create_dmda_slab(int32_t nx, int32_t ny, int32_t nz, double kappa, int32_t levels, pmg_grid g, pmg_dist dist, const int32_t *cuts, pmg_mgmc *mg);
 /* The same sampler on a hierarchy handed over level by level (level 0 = coarsest): the level operators and
    interpolations PCGAMGMC finds inside PETSc's PCMG / PCGAMG after PCSetUp (PCMGGetSmoother + PCGetOperators,
    PCMGGetInterpolation: src/pc_gamgmc.c:165-176), e.g. a GAMG hierarchy of an unstructured P1 matrix

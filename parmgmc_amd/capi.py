@@ -135,6 +135,10 @@ _sig = {
     "pmg_mgmc_set_smoother": (_int, [_vp, _int, _dbl, _int, _i32]),
     "pmg_mgmc_set_coarse": (_int, [_vp, _int, _i32]),
     "pmg_mgmc_set_keep_host": (_int, [_vp, _int]),
+    "pmg_mgmc_create_dmda_slab": (_int, [_i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pmg_dist_exchange": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmg_dist_allgather": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pmg_dist_get_info": (_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_int64)]),
     "pmg_mgmc_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_mgmc_set_correction_form": (_int, [_vp, _int]),
     "pmg_mgmc_setup": (_int, [_vp]),

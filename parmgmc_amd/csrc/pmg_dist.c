@@ -81,12 +81,16 @@ static pmg_status rccl_load(const char *path, pmg_rccl_api *api)
 #define PMG_IPC_MAXRANKS 64
 typedef struct {
   _Atomic uint64_t seq[PMG_IPC_MAXRANKS][2]; /* pushes of colour c issued by rank r */
+  _Atomic uint64_t gseq[PMG_IPC_MAXRANKS];   /* generic exchanges issued by rank r  */
 } pmg_ipc_shm;
 
 typedef struct {
   hipIpcMemHandle_t   mem;   /* the rank's receive block: recv[colour][side], `plane` doubles each */
   hipIpcEventHandle_t ev[2]; /* "my push of colour c has landed" */
   int64_t             plane; /* doubles per plane (must agree between neighbours) */
+  hipIpcMemHandle_t   gmem;   /* generic receive block: [parity][side][gcap] doubles */
+  hipIpcEventHandle_t gev[2]; /* "my generic push of parity p has landed" */
+  int64_t             gcap;
 } pmg_ipc_blob;
 
 struct pmg_dist_s {
@@ -101,6 +105,12 @@ struct pmg_dist_s {
   char          shm_name[64];
   uint64_t      round[2];        /* pushes of colour c issued so far */
   int64_t       plane;
+  /* generic neighbour exchange (V-cycle: residual planes, coarse-level planes, all-gather of a replicated level) */
+  double       *grecv, *peer_grecv[2];
+  hipEvent_t    gev[2], gevL[2], peer_gev[2][2];
+  int64_t       gcap;
+  uint64_t      ground;
+  hipEvent_t    evG, evGx;
   pmg_grid      g;
   int           rank, nranks, lo, hi; /* z-neighbours (-1 = physical boundary); lo == hi == rank in loopback mode */
   int           loopback;
@@ -160,6 +170,8 @@ pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void 
     if (hipEventCreateWithFlags(&d->evB[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evX[c], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   }
   if (!st && hipEventCreateWithFlags(&d->evS, hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+  if (!st && (hipEventCreateWithFlags(&d->evG, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evGx, hipEventDisableTiming) != hipSuccess)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+  d->gcap = (int64_t)1 << 40; /* RCCL moves data between the caller's buffers: no staging limit */
   if (st) {
     pmg_dist_destroy(&d);
     return st;
@@ -194,6 +206,13 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, const v
     if (hipEventCreateWithFlags(&d->evB[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evP[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ipc_ev[c], hipEventDisableTiming | hipEventInterprocess) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   }
   if (!st && hipEventCreateWithFlags(&d->evS, hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+  d->gcap = 2 * d->plane > ((int64_t)1 << 19) ? 2 * d->plane : ((int64_t)1 << 19); /* two colour planes of the fine level, or 4 MB */
+  if (!st && hipMalloc((void **)&d->grecv, sizeof(double) * 4 * (size_t)d->gcap) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipMalloc of the generic receive block failed");
+  if (!st && hipMemset(d->grecv, 0, sizeof(double) * 4 * (size_t)d->gcap) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+  for (int q = 0; q < 2 && !st; ++q) {
+    if (hipEventCreateWithFlags(&d->gev[q], hipEventDisableTiming | hipEventInterprocess) != hipSuccess || hipEventCreateWithFlags(&d->gevL[q], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+  }
+  if (!st && (hipEventCreateWithFlags(&d->evG, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evGx, hipEventDisableTiming) != hipSuccess)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   if (!st) { /* host-side sequence numbers in POSIX shared memory, named after the job token */
     const unsigned char *t = (const unsigned char *)token16;
     snprintf(d->shm_name, sizeof d->shm_name, "/pmg_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]);
@@ -229,6 +248,9 @@ pmg_status pmg_dist_ipc_export(pmg_dist d, void *blob)
   PMG_HIP(hipIpcGetMemHandle(&bl.mem, d->recv));
   for (int c = 0; c < 2; ++c) PMG_HIP(hipIpcGetEventHandle(&bl.ev[c], d->ipc_ev[c]));
   bl.plane = d->plane;
+  PMG_HIP(hipIpcGetMemHandle(&bl.gmem, d->grecv));
+  for (int q = 0; q < 2; ++q) PMG_HIP(hipIpcGetEventHandle(&bl.gev[q], d->gev[q]));
+  bl.gcap = d->gcap;
   memcpy(blob, &bl, sizeof bl);
   return PMG_SUCCESS;
 }
@@ -247,6 +269,9 @@ pmg_status pmg_dist_ipc_connect(pmg_dist d, const void *blob_lo, const void *blo
     PMG_CHECK(bl.plane == d->plane, PMG_ERR_ARG_SIZ, "neighbour plane size %lld != %lld", (long long)bl.plane, (long long)d->plane);
     PMG_HIP(hipIpcOpenMemHandle((void **)&d->peer_recv[side], bl.mem, hipIpcMemLazyEnablePeerAccess));
     for (int c = 0; c < 2; ++c) PMG_HIP(hipIpcOpenEventHandle(&d->peer_ev[side][c], bl.ev[c]));
+    PMG_CHECK(bl.gcap == d->gcap, PMG_ERR_ARG_SIZ, "neighbour exchange capacity %lld != %lld", (long long)bl.gcap, (long long)d->gcap);
+    PMG_HIP(hipIpcOpenMemHandle((void **)&d->peer_grecv[side], bl.gmem, hipIpcMemLazyEnablePeerAccess));
+    for (int q = 0; q < 2; ++q) PMG_HIP(hipIpcOpenEventHandle(&d->peer_gev[side][q], bl.gev[q]));
   }
   return PMG_SUCCESS;
 }
@@ -261,6 +286,8 @@ pmg_status pmg_dist_ipc_connect_loopback(pmg_dist d)
   for (int side = 0; side < 2; ++side) {
     d->peer_recv[side] = d->recv;
     for (int c = 0; c < 2; ++c) d->peer_ev[side][c] = d->evP[c]; /* recorded at the same point as the interprocess event */
+    d->peer_grecv[side] = d->grecv;
+    for (int q = 0; q < 2; ++q) d->peer_gev[side][q] = d->gevL[q];
   }
   return PMG_SUCCESS;
 }
@@ -366,9 +393,17 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
     (void)hipDeviceSynchronize();
     for (int side = 0; side < 2 && !d->loopback; ++side) {
       if (d->peer_recv[side]) (void)hipIpcCloseMemHandle(d->peer_recv[side]);
-      for (int c = 0; c < 2; ++c)
+      if (d->peer_grecv[side]) (void)hipIpcCloseMemHandle(d->peer_grecv[side]);
+      for (int c = 0; c < 2; ++c) {
         if (d->peer_ev[side][c]) (void)hipEventDestroy(d->peer_ev[side][c]);
+        if (d->peer_gev[side][c]) (void)hipEventDestroy(d->peer_gev[side][c]);
+      }
     }
+    for (int q = 0; q < 2; ++q) {
+      if (d->gev[q]) (void)hipEventDestroy(d->gev[q]);
+      if (d->gevL[q]) (void)hipEventDestroy(d->gevL[q]);
+    }
+    if (d->grecv) (void)hipFree(d->grecv);
     for (int c = 0; c < 2; ++c) {
       if (d->ipc_ev[c]) (void)hipEventDestroy(d->ipc_ev[c]);
       if (d->evP[c]) (void)hipEventDestroy(d->evP[c]);
@@ -382,9 +417,122 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
     if (d->evX[c]) (void)hipEventDestroy(d->evX[c]);
   }
   if (d->evS) (void)hipEventDestroy(d->evS);
+  if (d->evG) (void)hipEventDestroy(d->evG);
+  if (d->evGx) (void)hipEventDestroy(d->evGx);
   if (d->cs) (void)hipStreamDestroy(d->cs);
   free(d);
   *dp = NULL;
+  return PMG_SUCCESS;
+}
+
+/* ---- generic neighbour exchange ---------------------------------------------------------------------------------
+   One round trip with both z-neighbours on the caller's stream: up to PMG_XCH_MAXSEG contiguous segments per side.
+   What I send to my low neighbour arrives in ITS high receive buffers and vice versa; the segment sizes of a pair
+   must agree (sender's n_send = receiver's n_recv), sides without a neighbour are skipped, zero-length segments are
+   allowed.  Every rank must make the same sequence of calls (the IPC transport counts rounds).
+   RCCL: one grouped ncclSend/ncclRecv on the communication stream, between two event edges.
+   IPC : the segments are copied straight into the neighbour's generic receive block (two parities, so that round
+         r + 2 can be pushed while the neighbour still reads round r: it cannot have started r + 1's push, which I
+         wait for before r + 2, without having consumed r -- its streams are in order), then copied out locally. */
+pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo, const int64_t *nsend_lo, double *const *recv_lo, const int64_t *nrecv_lo, const double *const *send_hi, const int64_t *nsend_hi, double *const *recv_hi, const int64_t *nrecv_hi, void *stream)
+{
+  PMG_CHECK(d, PMG_ERR_ARG_NULL, "null dist object");
+  PMG_CHECK(nseg >= 0 && nseg <= PMG_XCH_MAXSEG, PMG_ERR_ARG_OUTOFRANGE, "nseg = %d", nseg);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->lo < 0 && d->hi < 0) return PMG_SUCCESS;
+  const double *const *snd[2] = {send_lo, send_hi};
+  double *const       *rcv[2] = {recv_lo, recv_hi};
+  const int64_t       *ns[2] = {nsend_lo, nsend_hi}, *nr[2] = {nrecv_lo, nrecv_hi};
+  const int            nb[2] = {d->lo, d->hi};
+  PMG_HIP(hipEventRecord(d->evG, s));
+  PMG_HIP(hipStreamWaitEvent(d->cs, d->evG, 0));
+  if (d->transport == 0) {
+    PMG_NCCL(d, d->api.GroupStart());
+    for (int side = 0; side < 2; ++side) {
+      if (nb[side] < 0) continue;
+      for (int q = 0; q < nseg; ++q) {
+        if (ns[side][q] > 0) PMG_NCCL(d, d->api.Send(snd[side][q], (size_t)ns[side][q], PMG_NCCL_DOUBLE, nb[side], d->comm, d->cs));
+        if (nr[side][q] > 0) PMG_NCCL(d, d->api.Recv(rcv[side][q], (size_t)nr[side][q], PMG_NCCL_DOUBLE, nb[side], d->comm, d->cs));
+      }
+    }
+    PMG_NCCL(d, d->api.GroupEnd());
+    PMG_HIP(hipEventRecord(d->evGx, d->cs));
+    PMG_HIP(hipStreamWaitEvent(s, d->evGx, 0));
+    return PMG_SUCCESS;
+  }
+  const int p = (int)(d->ground & 1);
+  for (int side = 0; side < 2; ++side) {
+    if (nb[side] < 0) continue;
+    int64_t off = 0;
+    for (int q = 0; q < nseg; ++q) {
+      PMG_CHECK(off + ns[side][q] <= d->gcap, PMG_ERR_ARG_SIZ, "exchange of %lld doubles exceeds the receive block (%lld)", (long long)(off + ns[side][q]), (long long)d->gcap);
+      if (ns[side][q] > 0) PMG_HIP(hipMemcpyAsync(d->peer_grecv[side] + (int64_t)(p * 2 + (1 - side)) * d->gcap + off, snd[side][q], sizeof(double) * (size_t)ns[side][q], hipMemcpyDeviceToDevice, d->cs));
+      off += ns[side][q];
+    }
+  }
+  PMG_HIP(hipEventRecord(d->gev[p], d->cs));
+  PMG_HIP(hipEventRecord(d->gevL[p], d->cs));
+  d->ground += 1;
+  atomic_store_explicit(&d->shm->gseq[d->rank], d->ground, memory_order_release);
+  for (int side = 0; side < 2; ++side) {
+    if (nb[side] < 0) continue;
+    uint64_t spins = 0;
+    while (atomic_load_explicit(&d->shm->gseq[nb[side]], memory_order_acquire) < d->ground) {
+      if (++spins > 4000000000ull) PMG_FAIL(PMG_ERR_LIB, "rank %d: neighbour %d never issued exchange %llu", d->rank, nb[side], (unsigned long long)d->ground);
+    }
+    PMG_HIP(hipStreamWaitEvent(s, d->peer_gev[side][p], 0));
+    int64_t off = 0;
+    for (int q = 0; q < nseg; ++q) {
+      if (nr[side][q] > 0) PMG_HIP(hipMemcpyAsync(rcv[side][q], d->grecv + (int64_t)(p * 2 + side) * d->gcap + off, sizeof(double) * (size_t)nr[side][q], hipMemcpyDeviceToDevice, s));
+      off += nr[side][q];
+    }
+  }
+  return PMG_SUCCESS;
+}
+
+/* every rank ends up with all blocks: block r = counts[r] doubles at buf + offsets[r], rank r owns block r.
+   RCCL: one group of sends to / receives from every other rank.  IPC (neighbour links only): nranks - 1 rounds of
+   passing blocks along the chain in both directions. */
+pmg_status pmg_dist_allgather(pmg_dist d, double *buf, const int64_t *offsets, const int64_t *counts, void *stream)
+{
+  PMG_CHECK(d && buf && offsets && counts, PMG_ERR_ARG_NULL, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (d->nranks == 1) return PMG_SUCCESS;
+  if (d->transport == 0) {
+    PMG_HIP(hipEventRecord(d->evG, s));
+    PMG_HIP(hipStreamWaitEvent(d->cs, d->evG, 0));
+    PMG_NCCL(d, d->api.GroupStart());
+    for (int r = 0; r < d->nranks; ++r) {
+      if (r == d->rank) continue;
+      if (counts[d->rank] > 0) PMG_NCCL(d, d->api.Send(buf + offsets[d->rank], (size_t)counts[d->rank], PMG_NCCL_DOUBLE, r, d->comm, d->cs));
+      if (counts[r] > 0) PMG_NCCL(d, d->api.Recv(buf + offsets[r], (size_t)counts[r], PMG_NCCL_DOUBLE, r, d->comm, d->cs));
+    }
+    PMG_NCCL(d, d->api.GroupEnd());
+    PMG_HIP(hipEventRecord(d->evGx, d->cs));
+    PMG_HIP(hipStreamWaitEvent(s, d->evGx, 0));
+    return PMG_SUCCESS;
+  }
+  for (int t = 1; t < d->nranks; ++t) {
+    /* upward: I pass block (rank - t + 1) to hi and receive block (rank - t) from lo; downward mirrored */
+    const int     up_s = d->rank - t + 1, up_r = d->rank - t, dn_s = d->rank + t - 1, dn_r = d->rank + t;
+    const double *shi = NULL, *slo = NULL;
+    double       *rlo = NULL, *rhi = NULL;
+    int64_t       nshi = 0, nslo = 0, nrlo = 0, nrhi = 0;
+    if (d->hi >= 0 && up_s >= 0) { shi = buf + offsets[up_s]; nshi = counts[up_s]; }
+    if (d->lo >= 0 && up_r >= 0) { rlo = buf + offsets[up_r]; nrlo = counts[up_r]; }
+    if (d->lo >= 0 && dn_s < d->nranks) { slo = buf + offsets[dn_s]; nslo = counts[dn_s]; }
+    if (d->hi >= 0 && dn_r < d->nranks) { rhi = buf + offsets[dn_r]; nrhi = counts[dn_r]; }
+    PMG_CALL(pmg_dist_exchange(d, 1, &slo, &nslo, &rlo, &nrlo, &shi, &nshi, &rhi, &nrhi, stream));
+  }
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_dist_get_info(pmg_dist d, int32_t *rank, int32_t *nranks, int64_t *capacity)
+{
+  PMG_CHECK(d, PMG_ERR_ARG_NULL, "null dist object");
+  if (rank) *rank = d->rank;
+  if (nranks) *nranks = d->nranks;
+  if (capacity) *capacity = d->gcap;
   return PMG_SUCCESS;
 }
 

@@ -42,6 +42,7 @@ pmg_status pmg_grid_sweep_color_faces_cvec(pmg_grid g, int color, int noisy, int
 /* kernel-side description of a grid object (internal) */
 pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L);
 
+#define PMG_XCH_MAXSEG 4
 /* low-rank (MATLRC) helper shared by pmg_mcsor and pmg_grid (pmg_lrc.c); vectors in the sampler's layout */
 typedef struct pmg_lrc_s *pmg_lrc;
 typedef pmg_status (*pmg_det_sweep_fn)(void *ctx, int dir, const double *b_lay, double *y_lay, void *stream);

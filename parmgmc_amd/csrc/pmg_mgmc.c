@@ -73,6 +73,12 @@ struct pmg_mgmc_s {
   int32_t   lrc_k;
   double   *lrc_B, *lrc_S;
   int       own_grid; /* the fine grid operator was created here (not handed in with a slab) */
+  /* multi-device: z-slabs of the fine grid, one rank per device (borrowed dist object); cuts[l*(nranks+1) + r] =
+     first plane of rank r on level l */
+  pmg_dist  dist;
+  int32_t   rank, nranks;
+  int32_t  *cuts;
+  int32_t   n_io; /* length of the caller's fine-level vectors (the owned planes) */
 };
 
 typedef struct {
@@ -293,7 +299,58 @@ pmg_status pmg_mgmc_create_dmda(int32_t nx, int32_t ny, int32_t nz, double kappa
           d[q] = (d[q] - 1) / 2 + 1;
         }
   }
-  *out = h;
+  h->n_io = nx * ny * nz;
+  *out    = h;
+  return PMG_SUCCESS;
+}
+
+/* The same sampler on z-slabs of the DMDA, one rank per device (the reference distributes every PCMG
+   level over all MPI ranks and lets GAMG reduce the coarse grids to rank 0, src/pc_chols.c:38-47,272-282):
+     - `g` is this rank's slab of the fine operator (pmg_grid_create with kz0 = cuts[rank], nz = cuts[rank+1] - kz0),
+       `dist` the halo transport created on it; both stay the caller's;
+     - a coarse plane K belongs to the owner of fine plane 2K, so coarse levels inherit the partition with no data
+       motion; per level and cycle there is the sweeps' halo (one plane per z-parity phase and side) and one halo of
+       the residual for the restriction; the prolongation also fills the fine ghost planes, from the coarse ghost
+       planes, so it needs no exchange;
+     - levels with at most PMG_MG_REPLICATE_BELOW (default 2^19) unknowns, or with fewer planes than ranks, are
+       REPLICATED: their right-hand side is all-gathered once and every rank runs the remaining coarse part of the
+       cycle redundantly -- the noise is a function of (seed, counter, global index), so all ranks compute the same
+       bits and no scatter is needed on the way up.
+   Samples are bit-identical to the single-device sampler for any number of ranks. */
+pmg_status pmg_mgmc_create_dmda_slab(int32_t nx, int32_t ny, int32_t nz, double kappa, int32_t levels, pmg_grid g, pmg_dist dist, const int32_t *cuts, pmg_mgmc *out)
+{
+  PMG_CHECK(out && g && dist && cuts, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CALL(pmg_mgmc_create_dmda(nx, ny, nz, kappa, levels, out));
+  pmg_mgmc   h  = *out;
+  pmg_status st = pmg_dist_get_info(dist, &h->rank, &h->nranks, NULL);
+  pmgk_grid_layout L;
+  if (!st) st = pmg_grid_get_kernel_layout(g, &L);
+  if (!st && (cuts[0] != 0 || cuts[h->nranks] != nz)) st = pmg_set_error(PMG_ERR_ARG_WRONG, __FILE__, __LINE__, "cuts must run from 0 to nz = %d", nz);
+  if (!st && (L.nx != nx || L.ny != ny || L.nzg != nz || L.kz0 != cuts[h->rank] || L.nz != cuts[h->rank + 1] - cuts[h->rank])) st = pmg_set_error(PMG_ERR_ARG_SIZ, __FILE__, __LINE__, "the grid slab does not match cuts[%d..%d] of a %d x %d x %d grid", h->rank, h->rank + 1, nx, ny, nz);
+  const int top = levels - 1;
+  if (!st) {
+    h->cuts = (int32_t *)malloc(sizeof(int32_t) * (size_t)levels * (size_t)(h->nranks + 1));
+    if (!h->cuts) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+  }
+  if (!st) {
+    const int nr1 = h->nranks + 1;
+    memcpy(h->cuts + (size_t)top * nr1, cuts, sizeof(int32_t) * (size_t)nr1);
+    for (int l = top; l >= 1 && !st; --l) {
+      if (h->lv[l].nz == h->lv[l - 1].nz) st = pmg_set_error(PMG_ERR_SUP, __FILE__, __LINE__, "z-slabs need a grid that is coarsened in z on every level");
+      for (int r = 0; r < nr1; ++r) h->cuts[(size_t)(l - 1) * nr1 + r] = (h->cuts[(size_t)l * nr1 + r] + 1) / 2; /* plane K <-> fine plane 2K */
+    }
+    for (int r = 0; r < h->nranks && !st; ++r)
+      if (cuts[r + 1] <= cuts[r]) st = pmg_set_error(PMG_ERR_ARG_WRONG, __FILE__, __LINE__, "rank %d owns no plane", r);
+  }
+  if (st) {
+    pmg_mgmc_destroy(out);
+    return st;
+  }
+  h->dist          = dist;
+  h->lv[top].g     = g;
+  h->lv[top].kz0   = L.kz0;
+  h->lv[top].nzl   = L.nz;
+  h->n_io          = nx * ny * L.nz;
   return PMG_SUCCESS;
 }
 
@@ -576,7 +633,8 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
   if (h->is_setup) return PMG_SUCCESS;
   if (h->user_hier) return mgmc_setup_user(h);
   const int top = h->nlevels - 1;
-  if (!h->keep_host && !h->lrc_k && !getenv("PMG_MG_FULL_GALERKIN") && !getenv("PMG_MG_NO_STENCIL") && !getenv("PMG_MG_CSR_TRANSFERS")) {
+  if (h->dist) PMG_CHECK(!h->keep_host && !h->lrc_k, PMG_ERR_SUP, "host copies and low-rank updates are single-device features");
+  if (h->dist || (!h->keep_host && !h->lrc_k && !getenv("PMG_MG_FULL_GALERKIN") && !getenv("PMG_MG_NO_STENCIL") && !getenv("PMG_MG_CSR_TRANSFERS"))) {
     /* class-stencil tables from the proxy hierarchy: no product with the full-size matrices */
     st27_table *tab = (st27_table *)malloc(sizeof(st27_table) * (size_t)top);
     PMG_CHECK(tab, PMG_ERR_MEM, "out of host memory");
@@ -585,6 +643,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
     if (!st && ok) st = mgmc_setup_stencil(h, tab);
     free(tab);
     if (st || ok) return st;
+    PMG_CHECK(!h->dist, PMG_ERR_SUP, "the coarse operators of this grid are not class stencils; z-slabs need them");
   }
   /* finest level: matrix-free grid operator */
   mg_level *F = &h->lv[top];
@@ -942,6 +1001,28 @@ static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
   PMG_CALL(pmg_grid_set_sweep_type(F->g, h->sweep_type));
   PMG_CALL(pmg_grid_cvec_len(F->g, &F->ld));
   F->grid_transfer = 1;
+  if (h->dist) { /* which levels stay distributed */
+    const int nr1 = h->nranks + 1;
+    int64_t   cap = 0, rep = (int64_t)1 << 19;
+    PMG_CALL(pmg_dist_get_info(h->dist, NULL, NULL, &cap));
+    if (getenv("PMG_MG_REPLICATE_BELOW")) rep = atoll(getenv("PMG_MG_REPLICATE_BELOW"));
+    F->distributed = h->nranks > 1;
+    int replicated = !F->distributed;
+    for (int l = top - 1; l >= 0; --l) {
+      mg_level      *Lv = &h->lv[l];
+      const int32_t *c  = h->cuts + (size_t)l * nr1;
+      int            minplanes = 1 << 30;
+      for (int r = 0; r < h->nranks; ++r) minplanes = c[r + 1] - c[r] < minplanes ? c[r + 1] - c[r] : minplanes;
+      if (!replicated && (Lv->n <= rep || minplanes < 1 || l == 0)) replicated = 1;
+      if (replicated) {
+        PMG_CHECK(!h->lv[l + 1].distributed || Lv->n <= cap, PMG_ERR_SUP, "level %d (%d unknowns) has to be replicated but exceeds the exchange capacity (%lld): use more levels", l, Lv->n, (long long)cap);
+      } else {
+        Lv->distributed = 1;
+        Lv->kz0         = c[h->rank];
+        Lv->nzl         = c[h->rank + 1] - c[h->rank];
+      }
+    }
+  }
   for (int l = top - 1; l >= 0; --l) {
     mg_level *Lv = &h->lv[l];
     level_set_padded(Lv);
@@ -974,7 +1055,38 @@ static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
   return PMG_SUCCESS;
 }
 
-/* `its` samples of the level sampler on a class-stencil level (same draw numbering as pmg_mcsor_sample_layout) */
+/* z-neighbour halo of a vector of a distributed level: the boundary planes travel to the neighbours' ghost planes */
+static pmg_status halo_level(pmg_mgmc h, mg_level *Lv, double *v, void *stream)
+{
+  if (!Lv->distributed) return PMG_SUCCESS;
+  const double *slo[2], *shi[2];
+  double       *rlo[2], *rhi[2];
+  int64_t       n[2];
+  int           nseg;
+  if (Lv->is_grid) { /* cvec: one block per colour */
+    nseg = 2;
+    for (int c = 0; c < 2; ++c) {
+      int64_t own, ghost;
+      PMG_CALL(pmg_grid_halo_plane(Lv->g, c, 0, &own, &ghost, &n[c]));
+      slo[c] = v + own;
+      rlo[c] = v + ghost;
+      PMG_CALL(pmg_grid_halo_plane(Lv->g, c, 1, &own, &ghost, &n[c]));
+      shi[c] = v + own;
+      rhi[c] = v + ghost;
+    }
+  } else {
+    nseg   = 1;
+    n[0]   = Lv->off;
+    slo[0] = v + Lv->off;
+    rlo[0] = v;
+    shi[0] = v + Lv->off * Lv->nzl;
+    rhi[0] = v + Lv->off * ((int64_t)Lv->nzl + 1);
+  }
+  return pmg_dist_exchange(h->dist, nseg, slo, n, rlo, n, shi, n, rhi, n, stream);
+}
+
+/* `its` samples of the level sampler on a class-stencil level (same draw numbering as pmg_mcsor_sample_layout); on a
+   z-slab the two z-parity phases of a sweep are separated by a halo of the boundary planes */
 static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, uint64_t *ctr, void *stream)
 {
   pmgk_st27 S = Lv->st;
@@ -985,7 +1097,14 @@ static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, 
       const int     backward = ndir == 2 ? d : h->sweep_type == PMG_SOR_BACKWARD_SWEEP;
       const double *rhs      = Lv->b;
       if (Lv->lrc) PMG_CALL(pmg_lrc_rhs(Lv->lrc, Lv->b, seed, *ctr, &rhs, stream)); /* + B (sqrt(S) o eta), src/pc_mcgibbs.c:130-140 */
-      PMG_KERNEL(pmgk_st27_sweep(&S, backward, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
+      if (Lv->distributed) {
+        PMG_KERNEL(pmgk_st27_sweep_phase(&S, backward, 0, h->omega, 1, seed, *ctr, rhs, Lv->x, stream));
+        PMG_CALL(halo_level(h, Lv, Lv->x, stream));
+        PMG_KERNEL(pmgk_st27_sweep_phase(&S, backward, 1, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
+        PMG_CALL(halo_level(h, Lv, Lv->x, stream));
+      } else {
+        PMG_KERNEL(pmgk_st27_sweep(&S, backward, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
+      }
       if (Lv->lrc) PMG_CALL(pmg_lrc_post(Lv->lrc, backward ? PMG_SOR_BACKWARD_SWEEP : PMG_SOR_FORWARD_SWEEP, Lv->x, stream)); /* src/mc_sor.c:101-112 */
     }
   }
@@ -998,7 +1117,8 @@ static uint64_t level_seed(uint64_t seed, int level) { return seed + 0x9E3779B97
 static pmg_status mg_smooth(pmg_mgmc h, int l, uint64_t seed, uint64_t *ctr, void *stream)
 {
   mg_level *Lv = &h->lv[l];
-  if (Lv->is_grid) PMG_CALL(pmg_grid_sample_cvec(Lv->g, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
+  if (Lv->is_grid && h->dist) PMG_CALL(pmg_dist_sample_cvec(h->dist, Lv->b, Lv->x, h->nu, h->scaled, h->sweep_type, level_seed(seed, l), *ctr, ctr, stream)); /* leaves the ghost planes current */
+  else if (Lv->is_grid) PMG_CALL(pmg_grid_sample_cvec(Lv->g, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
   else if (Lv->is_st27) PMG_CALL(st27_sample(h, Lv, h->nu, level_seed(seed, l), ctr, stream));
   else PMG_CALL(pmg_mcsor_sample_layout(Lv->mc, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
   return PMG_SUCCESS;
@@ -1022,16 +1142,36 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* PCMGSetResidual(..., As[l]), src/pc_gamgmc.c:194 */
     }
     else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
+    /* a z-slab restricts into the coarse planes it owns (K with fine plane 2K on this rank) and needs r on its ghost
+       planes for that; into a replicated coarse level the owned part is followed by an all-gather */
+    pmgk_st27_dims CD   = level_dims(Cc);
+    double        *bc   = Cc->b;
+    const int      fold = Lv->distributed && !Cc->distributed; /* distributed -> replicated */
+    const int32_t *cc   = h->dist ? h->cuts + (size_t)(l - 1) * (size_t)(h->nranks + 1) : NULL;
+    if (Lv->distributed) PMG_CALL(halo_level(h, Lv, Lv->r, stream));
+    if (fold) {
+      CD.kz0 = cc[h->rank];
+      CD.nz  = cc[h->rank + 1] - cc[h->rank];
+      bc     = Cc->b + Cc->off * CD.kz0; /* plane K of the full-size vector = plane K - kz0 of the shifted one */
+    }
     if (Lv->grid_transfer) { /* MatRestrict, matrix-free */
-      pmgk_grid_layout     GL;
-      const pmgk_st27_dims CD = level_dims(Cc);
+      pmgk_grid_layout GL;
       PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
-      PMG_KERNEL(pmgk_q1_restrict(&GL, &CD, Lv->cpos_dev, Lv->r, Cc->b, stream));
+      PMG_KERNEL(pmgk_q1_restrict(&GL, &CD, Lv->cpos_dev, Lv->r, bc, stream));
     } else if (Lv->nat_transfer) {
-      const pmgk_st27_dims FD = level_dims(Lv), CD = level_dims(Cc);
-      PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, Lv->r, Cc->b, stream));
+      const pmgk_st27_dims FD = level_dims(Lv);
+      PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, Lv->r, bc, stream));
     } else {
       PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, Lv->r, Cc->b, 0, stream)); /* MatRestrict */
+    }
+    if (fold) {
+      int64_t offs[64], cnts[64];
+      PMG_CHECK(h->nranks <= 64, PMG_ERR_ARG_OUTOFRANGE, "too many ranks");
+      for (int r = 0; r < h->nranks; ++r) {
+        offs[r] = Cc->off * ((int64_t)cc[r] + 1);
+        cnts[r] = Cc->off * (int64_t)(cc[r + 1] - cc[r]);
+      }
+      PMG_CALL(pmg_dist_allgather(h->dist, Cc->b, offs, cnts, stream));
     }
   }
   {
@@ -1046,14 +1186,17 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
   }
   for (int l = 1; l <= top; ++l) {
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
+    /* a z-slab also interpolates onto its in-domain ghost planes (from its coarse planes + coarse ghost planes): the
+       same arithmetic the owner does, so the fine ghost planes stay current without an exchange */
+    const int glo = Lv->distributed && Lv->kz0 > 0, ghi = Lv->distributed && Lv->kz0 + Lv->nzl < Lv->nz;
     if (Lv->grid_transfer) { /* MatInterpolateAdd, matrix-free */
       pmgk_grid_layout     GL;
       const pmgk_st27_dims CD = level_dims(Cc);
       PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
-      PMG_KERNEL(pmgk_q1_prolong_add(&GL, &CD, Lv->cpos_dev, 0, Lv->nzl, Cc->x, Lv->x, stream));
+      PMG_KERNEL(pmgk_q1_prolong_add(&GL, &CD, Lv->cpos_dev, -glo, Lv->nzl + glo + ghi, Cc->x, Lv->x, stream));
     } else if (Lv->nat_transfer) {
       const pmgk_st27_dims FD = level_dims(Lv), CD = level_dims(Cc);
-      PMG_KERNEL(pmgk_st27_prolong_add(&FD, &CD, Lv->kz0, Lv->nzl, Cc->x, Lv->x, stream));
+      PMG_KERNEL(pmgk_st27_prolong_add(&FD, &CD, Lv->kz0 - glo, Lv->nzl + glo + ghi, Cc->x, Lv->x, stream));
     } else {
       PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, Cc->x, Lv->x, 1, stream)); /* MatInterpolateAdd */
     }
@@ -1080,6 +1223,7 @@ pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32
   const size_t bytes = sizeof(double) * (size_t)F->ld;
   PMG_CALL(lvl_to_layout(F, b_nat, h->b_lay, stream));
   PMG_CALL(lvl_to_layout(F, y_nat, h->y_lay, stream));
+  if (h->correction_form && F->distributed) PMG_CALL(halo_level(h, F, h->y_lay, stream)); /* the outer residual reads the ghost planes of y */
   for (int32_t it = 0; it < its; ++it) {
     if (!h->correction_form) {
       /* The cycle run IN PLACE on (b, y): a stationary linear sweep satisfies S(b, y) = y + S(b - A y, 0) with the
@@ -1105,7 +1249,7 @@ pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32
     }
     if (cb) { /* pg->scb(it, y, ctx), src/pc_gamgmc.c:258 */
       PMG_CALL(lvl_from_layout(F, h->y_lay, y_nat, stream));
-      const int rc = cb(it, y_nat, F->n, cbctx);
+      const int rc = cb(it, y_nat, h->n_io, cbctx);
       PMG_CHECK(rc == 0, rc, "sample callback returned %d", rc);
     }
   }
@@ -1147,6 +1291,7 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
   pmg_dev_free(h->b_lay);
   free(h->lrc_B);
   free(h->lrc_S);
+  free(h->cuts);
   free(h->lv);
   free(h);
   *hp = NULL;

@@ -241,3 +241,44 @@ class DistGridSampler:
             return self.rccl.sample_cvec(b, y, its, self.scaled, self.sweep_type, seed, counter0)
         g = self.grid
         return run_samples(lambda c, k0, nk, bb, yy, ctr: g.sweep_color_planes_cvec(c, k0, nk, bb, yy, True, self.scaled, seed, ctr), self.halo, g.nz, b, y, its, self.sweep_type, counter0)
+
+
+class DistMGMC:
+    """Multigrid Monte Carlo on `world` GPUs (this process = one z-slab of every distributed level): the C V-cycle of
+    pmg_mgmc.c on top of the halo transport of pmg_dist.c ("ipc" or "rccl"; reference PCGAMGMC over MPI ranks,
+    src/pc_gamgmc.c + src/mc_sor.c:298-381).  b and y of `sample` are this rank's planes in natural order."""
+
+    def __init__(self, nx, ny, nz, kappa, levels, rank, world, group=None, transport=None):
+        import ctypes as C
+
+        import numpy as np
+
+        from .capi import check, lib
+        from .wrappers import MGMC
+
+        self.rank, self.world = rank, world
+        self.cuts = slab_cuts(nz, world)
+        if world == 1:
+            self.grid_sampler, self.transport = None, "none"
+            self.mg = MGMC(nx, ny, nz, kappa, levels)
+        else:
+            self.grid_sampler = DistGridSampler(nx, ny, nz, kappa, rank, world, group=group, transport=transport)
+            self.transport = self.grid_sampler.transport
+            if self.grid_sampler.rccl is None:
+                raise RuntimeError("the distributed V-cycle needs the ipc or rccl halo transport (torch P2P carries only the stand-alone sweeps)")
+            cuts = np.asarray(self.cuts, np.int32)
+            mg = MGMC.__new__(MGMC)
+            mg.nx, mg.ny, mg.nz, mg.levels = nx, ny, nz, levels
+            mg._h = C.c_void_p()
+            check(lib.pmg_mgmc_create_dmda_slab(nx, ny, nz, kappa, levels, self.grid_sampler.grid._h, self.grid_sampler.rccl._h, cuts.ctypes.data, C.byref(mg._h)))
+            mg.n = nx * ny * (self.cuts[rank + 1] - self.cuts[rank])
+            self.mg = mg
+        self.n_local = nx * ny * (self.cuts[rank + 1] - self.cuts[rank])
+        self.plane_range = (self.cuts[rank], self.cuts[rank + 1])
+
+    def __getattr__(self, name):  # set_smoother, set_coarse, set_correction_form, setup, sample, ...
+        return getattr(self.mg, name)
+
+    def destroy(self):
+        self.mg.destroy()  # before the transport and the grid it borrows
+        self.grid_sampler = None

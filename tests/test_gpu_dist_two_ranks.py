@@ -107,3 +107,83 @@ def test_rccl_driver_loopback_on_one_gpu():
         for side in (0, 1):
             own, ghost, n = g.halo_plane(c, side)
             assert torch.equal(y[ghost:ghost + n], y[own:own + n]) and float(y[own:own + n].abs().sum()) > 0
+
+
+def _mg_worker(rank, world, port, grid, kappa, levels, opts, its, q, transport):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for k, v in opts.get("env", {}).items():
+        os.environ[k] = v
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from parmgmc_amd.dist import DistMGMC
+
+    nx, ny, nz = grid
+    mg = DistMGMC(nx, ny, nz, kappa, levels, rank, world, transport=transport)
+    mg.set_smoother(opts["scaled"], opts["omega"], opts["sweep"], opts["nu"])
+    mg.set_coarse(opts["coarse"], opts["coarse_its"])
+    mg.set_correction_form(opts["literal"])
+    mg.setup()
+    rng = np.random.default_rng(5)
+    b_all, y_all = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
+    lo, hi = mg.plane_range[0] * nx * ny, mg.plane_range[1] * nx * ny
+    b = torch.as_tensor(b_all[lo:hi], device="cuda")
+    y = torch.as_tensor(y_all[lo:hi], device="cuda")
+    seen = []
+    ctr = mg.sample(b, y, its - 1, seed=42, counter0=1, callback=lambda it, yy: seen.append(yy.cpu().numpy().copy()))
+    ctr = mg.sample(b, y, 1, seed=42, counter0=ctr)  # a second call continues the chain
+    torch.cuda.synchronize()
+    q.put((rank, y.cpu().numpy(), ctr, seen))
+    dist.barrier()
+    mg.destroy()
+    dist.destroy_process_group()
+
+
+MG_DEFAULT = dict(scaled=False, omega=1.0, sweep=1, nu=1, coarse="cholsampler", coarse_its=1, literal=False, env={})
+
+
+@pytest.mark.parametrize("grid,levels,world,opts", [
+    ((17, 17, 17), 3, 2, {}),                                                             # 17 -> 9 -> 5: everything below the grid level replicated
+    ((17, 17, 33), 4, 3, {"env": {"PMG_MG_REPLICATE_BELOW": "400"}}),                      # distributed class-stencil levels, uneven slabs
+    ((33, 17, 33), 4, 4, {"env": {"PMG_MG_REPLICATE_BELOW": "2000"}, "scaled": True, "omega": 1.2, "sweep": 3, "nu": 2, "coarse": "gibbs", "coarse_its": 2}),
+    ((17, 9, 33), 3, 2, {"env": {"PMG_MG_REPLICATE_BELOW": "100"}, "literal": True, "sweep": 2, "scaled": True}),
+], ids=["replicated", "slab_levels_3ranks", "symmetric_gibbs_coarse_4ranks", "literal_backward"])
+def test_distributed_vcycle_reproduces_the_single_device_chain(grid, levels, world, opts):
+    """z-slab MGMC (pmg_mgmc_create_dmda_slab) with `world` ranks sharing the one GPU over the ipc transport: sweeps
+    with per-phase halos, residual halo + restriction, all-gather into the replicated coarse part, prolongation onto
+    ghost planes -- bit-identical to the single-device sampler, sample by sample."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from parmgmc_amd import MGMC
+
+    o = dict(MG_DEFAULT, **opts)
+    kappa, its = 1.5, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mg_worker, args=(r, world, port, grid, kappa, levels, o, its, q, "ipc")) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = int(np.prod(grid))
+    rng = np.random.default_rng(5)
+    b_all, y_all = rng.standard_normal(n), rng.standard_normal(n)
+    one = MGMC(*grid, kappa, levels)
+    one.set_smoother(o["scaled"], o["omega"], o["sweep"], o["nu"])
+    one.set_coarse(o["coarse"], o["coarse_its"])
+    one.set_correction_form(o["literal"])
+    one.setup()
+    yd = torch.as_tensor(y_all, device="cuda")
+    want = []
+    ctr = one.sample(torch.as_tensor(b_all, device="cuda"), yd, its, seed=42, counter0=1, callback=lambda it, yy: want.append(yy.cpu().numpy().copy()))
+    assert all(x[2] == ctr for x in parts)
+    for it in range(its - 1):  # every intermediate sample, as the callback saw it
+        assert np.array_equal(np.concatenate([x[3][it] for x in parts]), want[it])
+    assert np.array_equal(np.concatenate([x[1] for x in parts]), yd.cpu().numpy())
