@@ -14,12 +14,13 @@
  * only: the chain is bit-identical for every number of devices.
  *
  * Second transport, "ipc" (same schedule, for the latency-bound strong-scaling regime where a 1 MB RCCL send/recv
- * kernel costs ~40 us): every rank owns a small receive block (one plane per colour and side) exported with
- * hipIpcGetMemHandle; a push is a plain device-to-device copy of the boundary plane INTO the neighbour's block over
- * xGMI, followed by an interprocess event; the receiver waits on that event in its compute stream and copies the
- * plane into its ghost plane.  hipStreamWaitEvent binds to the most recent record at call time, so a host-side
- * sequence number in POSIX shared memory tells the receiver that the sender has ISSUED the record of the round it
- * needs (hosts run in lockstep anyway; no GPU ever spins).
+ * kernel costs ~40 us): every rank owns one receive block (flag words, one plane per colour and side, a generic
+ * message area) exported with hipIpcGetMemHandle.  A push writes the boundary plane INTO the neighbour's block over
+ * xGMI (the face kernel stores there directly) and then raises a flag word in the same block to the round number
+ * with hipStreamWriteValue64; the receiver's stream waits for the flag with hipStreamWaitValue64 and reads the
+ * plane.  Everything is stream-ordered on the devices: no host rendezvous, no interprocess events (the runtime
+ * caps those at 32 records and services every wait on one from a host thread), ~9 us per flag round trip measured
+ * between two processes.  The host only throttles itself to a few rounds ahead of its device.
  *
  * RCCL is loaded at run time (dlopen of the path the caller names -- the copy PyTorch bundles when used beside
  * torch, so that the process keeps one RCCL and one HIP runtime); no link-time dependency.
@@ -27,10 +28,6 @@
 #define _GNU_SOURCE
 #include "pmg_internal.h"
 #include <dlfcn.h>
-#include <fcntl.h>
-#include <stdatomic.h>
-#include <sys/mman.h>
-#include <unistd.h>
 
 typedef struct {
   char internal[128];
@@ -79,38 +76,31 @@ static pmg_status rccl_load(const char *path, pmg_rccl_api *api)
   } while (0)
 
 #define PMG_IPC_MAXRANKS 64
+#define PMG_IPC_WINDOW 8
+#define PMG_IPC_HDR 512 /* doubles reserved at the start of a receive block for the flag words */
+/* flag words (uint64) at the start of a receive block: [c*2 + side] = round of the latest colour-c plane pushed into
+   slot (c, side); [4 + side] = round of the latest generic message pushed into side `side` */
 typedef struct {
-  _Atomic uint64_t seq[PMG_IPC_MAXRANKS][2]; /* pushes of colour c issued by rank r */
-  _Atomic uint64_t gseq[PMG_IPC_MAXRANKS];   /* generic exchanges issued by rank r  */
-} pmg_ipc_shm;
-
-typedef struct {
-  hipIpcMemHandle_t   mem;   /* the rank's receive block: recv[colour][side], `plane` doubles each */
-  hipIpcEventHandle_t ev[2]; /* "my push of colour c has landed" */
-  int64_t             plane; /* doubles per plane (must agree between neighbours) */
-  hipIpcMemHandle_t   gmem;   /* generic receive block: [parity][side][gcap] doubles */
-  hipIpcEventHandle_t gev[2]; /* "my generic push of parity p has landed" */
-  int64_t             gcap;
+  hipIpcMemHandle_t mem;   /* the rank's receive block */
+  int64_t           plane; /* doubles per plane (must agree between neighbours) */
+  int64_t           gcap;  /* doubles per generic message slot */
 } pmg_ipc_blob;
 
 struct pmg_dist_s {
-  int           transport; /* 0 = RCCL, 1 = IPC peer copies */
-  /* ipc */
-  double       *recv;            /* own receive block (4 planes) */
-  double       *peer_recv[2];    /* neighbours' receive blocks, mapped (side 0 = lo, 1 = hi) */
-  hipEvent_t    ipc_ev[2];       /* own interprocess events */
-  hipEvent_t    peer_ev[2][2];   /* [side][colour] neighbours' events */
-  hipEvent_t    evP[2];          /* local: push of colour c has read my boundary planes */
-  pmg_ipc_shm  *shm;
-  char          shm_name[64];
-  uint64_t      round[2];        /* pushes of colour c issued so far */
-  int64_t       plane;
-  /* generic neighbour exchange (V-cycle: residual planes, coarse-level planes, all-gather of a replicated level) */
+  int           transport; /* 0 = RCCL, 1 = IPC peer stores + flag words */
+  /* ipc: block = [PMG_IPC_HDR flag doubles][recv: 4 planes][grecv: 2 parities x 2 sides x gcap] */
+  double       *block, *peer_block[2]; /* own / neighbours' blocks (side 0 = lo, 1 = hi) */
+  double       *recv, *peer_recv[2];
   double       *grecv, *peer_grecv[2];
-  hipEvent_t    gev[2], gevL[2], peer_gev[2][2];
-  int64_t       gcap;
-  uint64_t      ground;
-  hipEvent_t    evG, evGx;
+  uint64_t      round[2];              /* pushes of colour c issued so far */
+  uint64_t      ground;                /* generic exchanges issued so far  */
+  int64_t       plane, gcap;
+  hipEvent_t    evP[2];                /* local: the initial push of colour c has read my boundary planes */
+  hipEvent_t    evW[2];                /* local: the neighbours' current colour-c planes have landed in my block */
+  hipEvent_t    evT[PMG_IPC_WINDOW];   /* ring: compute-stream progress (interior planes of a colour done); also the host run-ahead throttle */
+  uint64_t      nthrottle;
+  hipEvent_t    evF[2];                /* local: face planes of colour c done (face stream) */
+  unsigned     *err_dev;               /* pinned host word (device-visible), set by a flag wait that gave up */
   pmg_grid      g;
   int           rank, nranks, lo, hi; /* z-neighbours (-1 = physical boundary); lo == hi == rank in loopback mode */
   int           loopback;
@@ -120,6 +110,7 @@ struct pmg_dist_s {
   hipEvent_t    evB[2];   /* boundary planes of colour c swept */
   hipEvent_t    evX[2];   /* exchange of colour c complete     */
   hipEvent_t    evS;      /* caller's stream reached the call  */
+  hipEvent_t    evG, evGx; /* generic exchange edges (RCCL)    */
   int32_t       nz;
 };
 
@@ -184,7 +175,8 @@ pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void 
 
 pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, const void *token16, pmg_dist *out)
 {
-  PMG_CHECK(out && g && token16, PMG_ERR_ARG_NULL, "null argument");
+  (void)token16; /* job token of the first version of this transport (host-side sequence numbers); unused */
+  PMG_CHECK(out && g, PMG_ERR_ARG_NULL, "null argument");
   *out = NULL;
   PMG_CHECK(nranks >= 1 && nranks <= PMG_IPC_MAXRANKS && rank >= 0 && rank < nranks, PMG_ERR_ARG_OUTOFRANGE, "rank %d of %d", rank, nranks);
   pmg_dist d = (pmg_dist)calloc(1, sizeof *d);
@@ -199,32 +191,23 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, const v
   pmg_status       st = pmg_grid_get_kernel_layout(g, &L);
   d->nz               = L.nz;
   d->plane            = L.sp;
-  if (!st && hipMalloc((void **)&d->recv, sizeof(double) * 4 * (size_t)d->plane) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipMalloc of the halo receive block failed");
-  if (!st && hipMemset(d->recv, 0, sizeof(double) * 4 * (size_t)d->plane) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+  d->gcap             = 2 * d->plane > ((int64_t)1 << 19) ? 2 * d->plane : ((int64_t)1 << 19); /* two colour planes of the fine level, or 4 MB */
+  const size_t bytes  = sizeof(double) * (size_t)(PMG_IPC_HDR + 4 * d->plane + 4 * d->gcap);
+  if (!st && hipMalloc((void **)&d->block, bytes) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipMalloc of the halo receive block failed");
+  if (!st && hipMemset(d->block, 0, bytes) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+  d->recv  = d->block ? d->block + PMG_IPC_HDR : NULL;
+  d->grecv = d->block ? d->recv + 4 * d->plane : NULL;
   if (!st && hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "stream creation failed");
   for (int c = 0; c < 2 && !st; ++c) {
-    if (hipEventCreateWithFlags(&d->evB[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evP[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ipc_ev[c], hipEventDisableTiming | hipEventInterprocess) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+    if (hipEventCreateWithFlags(&d->evB[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evP[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evW[c], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   }
   if (!st && hipEventCreateWithFlags(&d->evS, hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
-  d->gcap = 2 * d->plane > ((int64_t)1 << 19) ? 2 * d->plane : ((int64_t)1 << 19); /* two colour planes of the fine level, or 4 MB */
-  if (!st && hipMalloc((void **)&d->grecv, sizeof(double) * 4 * (size_t)d->gcap) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipMalloc of the generic receive block failed");
-  if (!st && hipMemset(d->grecv, 0, sizeof(double) * 4 * (size_t)d->gcap) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
-  for (int q = 0; q < 2 && !st; ++q) {
-    if (hipEventCreateWithFlags(&d->gev[q], hipEventDisableTiming | hipEventInterprocess) != hipSuccess || hipEventCreateWithFlags(&d->gevL[q], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
-  }
-  if (!st && (hipEventCreateWithFlags(&d->evG, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evGx, hipEventDisableTiming) != hipSuccess)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
-  if (!st) { /* host-side sequence numbers in POSIX shared memory, named after the job token */
-    const unsigned char *t = (const unsigned char *)token16;
-    snprintf(d->shm_name, sizeof d->shm_name, "/pmg_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]);
-    const int fd = shm_open(d->shm_name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)sizeof(pmg_ipc_shm)) != 0) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "shm_open(%s) failed", d->shm_name);
-    if (!st) {
-      void *m = mmap(NULL, sizeof(pmg_ipc_shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-      if (m == MAP_FAILED) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "mmap of %s failed", d->shm_name);
-      else d->shm = (pmg_ipc_shm *)m;
-    }
-    if (fd >= 0) close(fd);
-  }
+  for (int q = 0; q < PMG_IPC_WINDOW && !st; ++q)
+    if (hipEventCreateWithFlags(&d->evT[q], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+  for (int c = 0; c < 2 && !st; ++c)
+    if (hipEventCreateWithFlags(&d->evF[c], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+  if (!st && hipHostMalloc((void **)&d->err_dev, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipHostMalloc failed");
+  if (!st) *d->err_dev = 0;
   if (st) {
     pmg_dist_destroy(&d);
     return st;
@@ -245,12 +228,9 @@ pmg_status pmg_dist_ipc_export(pmg_dist d, void *blob)
   PMG_CHECK(d && blob && d->transport == 1, PMG_ERR_ARG_WRONG, "not an IPC dist object");
   pmg_ipc_blob bl;
   memset(&bl, 0, sizeof bl);
-  PMG_HIP(hipIpcGetMemHandle(&bl.mem, d->recv));
-  for (int c = 0; c < 2; ++c) PMG_HIP(hipIpcGetEventHandle(&bl.ev[c], d->ipc_ev[c]));
+  PMG_HIP(hipIpcGetMemHandle(&bl.mem, d->block));
   bl.plane = d->plane;
-  PMG_HIP(hipIpcGetMemHandle(&bl.gmem, d->grecv));
-  for (int q = 0; q < 2; ++q) PMG_HIP(hipIpcGetEventHandle(&bl.gev[q], d->gev[q]));
-  bl.gcap = d->gcap;
+  bl.gcap  = d->gcap;
   memcpy(blob, &bl, sizeof bl);
   return PMG_SUCCESS;
 }
@@ -266,121 +246,143 @@ pmg_status pmg_dist_ipc_connect(pmg_dist d, const void *blob_lo, const void *blo
     PMG_CHECK(blobs[side], PMG_ERR_ARG_NULL, "missing blob of neighbour rank %d", nb[side]);
     pmg_ipc_blob bl;
     memcpy(&bl, blobs[side], sizeof bl);
-    PMG_CHECK(bl.plane == d->plane, PMG_ERR_ARG_SIZ, "neighbour plane size %lld != %lld", (long long)bl.plane, (long long)d->plane);
-    PMG_HIP(hipIpcOpenMemHandle((void **)&d->peer_recv[side], bl.mem, hipIpcMemLazyEnablePeerAccess));
-    for (int c = 0; c < 2; ++c) PMG_HIP(hipIpcOpenEventHandle(&d->peer_ev[side][c], bl.ev[c]));
-    PMG_CHECK(bl.gcap == d->gcap, PMG_ERR_ARG_SIZ, "neighbour exchange capacity %lld != %lld", (long long)bl.gcap, (long long)d->gcap);
-    PMG_HIP(hipIpcOpenMemHandle((void **)&d->peer_grecv[side], bl.gmem, hipIpcMemLazyEnablePeerAccess));
-    for (int q = 0; q < 2; ++q) PMG_HIP(hipIpcOpenEventHandle(&d->peer_gev[side][q], bl.gev[q]));
+    PMG_CHECK(bl.plane == d->plane && bl.gcap == d->gcap, PMG_ERR_ARG_SIZ, "neighbour receive block (%lld, %lld) != (%lld, %lld)", (long long)bl.plane, (long long)bl.gcap, (long long)d->plane, (long long)d->gcap);
+    PMG_HIP(hipIpcOpenMemHandle((void **)&d->peer_block[side], bl.mem, hipIpcMemLazyEnablePeerAccess));
+    d->peer_recv[side]  = d->peer_block[side] + PMG_IPC_HDR;
+    d->peer_grecv[side] = d->peer_recv[side] + 4 * d->plane;
   }
   return PMG_SUCCESS;
 }
 
 /* single rank as its own z-neighbour for the halo only (timing / smoke test on one GPU, like the RCCL loopback):
-   the "peer" receive block and events are the rank's own, no IPC handle is opened */
+   the "peer" receive block is the rank's own, no IPC handle is opened */
 pmg_status pmg_dist_ipc_connect_loopback(pmg_dist d)
 {
   PMG_CHECK(d && d->transport == 1 && d->nranks == 1, PMG_ERR_ARG_WRONG, "loopback needs a single-rank IPC dist object");
   d->lo = d->hi = 0;
   d->loopback   = 1;
   for (int side = 0; side < 2; ++side) {
-    d->peer_recv[side] = d->recv;
-    for (int c = 0; c < 2; ++c) d->peer_ev[side][c] = d->evP[c]; /* recorded at the same point as the interprocess event */
+    d->peer_block[side] = d->block;
+    d->peer_recv[side]  = d->recv;
     d->peer_grecv[side] = d->grecv;
-    for (int q = 0; q < 2; ++q) d->peer_gev[side][q] = d->gevL[q];
   }
   return PMG_SUCCESS;
 }
 
-/* rank 0, after every rank has mapped it: remove the name of the shared-memory object */
+/* kept for callers of the first version of this transport (it removed a POSIX shared-memory name); nothing to do */
 pmg_status pmg_dist_ipc_unlink(pmg_dist d)
 {
   PMG_CHECK(d && d->transport == 1, PMG_ERR_ARG_WRONG, "not an IPC dist object");
-  if (d->shm_name[0]) shm_unlink(d->shm_name);
   return PMG_SUCCESS;
 }
 
-/* Initial push (start of a call): copy my boundary planes of colour c into the neighbours' receive blocks on the comm
-   stream.  Later pushes are done by the face kernel itself (HALO mode), see ipc_sample. */
-static pmg_status ipc_push_copy(pmg_dist d, int c, const double *y, hipEvent_t after)
+/* call once per round on the stream the round's work was queued on: blocks the host until the round issued
+   PMG_IPC_WINDOW rounds ago has finished on the device (bounded queue depth, nothing more) */
+static pmg_status ipc_throttle(pmg_dist d, hipStream_t s)
 {
-  PMG_HIP(hipStreamWaitEvent(d->cs, after, 0));
-  int64_t own, ghost, n;
-  for (int side = 0; side < 2; ++side) {
-    if ((side == 0 ? d->lo : d->hi) < 0) continue;
-    PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
-    /* my low plane lands in the neighbour's HIGH slot and vice versa: recv[(c*2 + their_side) * plane] */
-    double *dst = d->peer_recv[side] + (int64_t)(c * 2 + (1 - side)) * d->plane;
-    PMG_HIP(hipMemcpyAsync(dst, y + own, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, d->cs));
-  }
-  PMG_HIP(hipEventRecord(d->ipc_ev[c], d->cs)); /* neighbours wait on this */
-  PMG_HIP(hipEventRecord(d->evP[c], d->cs));    /* local twin: I wait on it before rewriting the planes */
-  d->round[c] += 1;
-  atomic_store_explicit(&d->shm->seq[d->rank][c], d->round[c], memory_order_release);
+  const int slot = (int)(d->nthrottle % PMG_IPC_WINDOW);
+  if (d->nthrottle >= PMG_IPC_WINDOW) PMG_HIP(hipEventSynchronize(d->evT[slot]));
+  PMG_HIP(hipEventRecord(d->evT[slot], s));
+  d->nthrottle += 1;
   return PMG_SUCCESS;
 }
 
-/* make stream s wait until both neighbours' pushes number round[c] of colour c have landed in my receive block */
-static pmg_status ipc_wait(pmg_dist d, int c, hipStream_t s)
+/* flag words: mine = (uint64_t *)block, the neighbours' = (uint64_t *)peer_block[side].  Index c*2 + slot for the
+   colour planes (slot = the side of the RECEIVER the plane comes from), 4 + slot for generic messages. */
+static uint64_t *flag_mine(pmg_dist d, int idx) { return (uint64_t *)d->block + idx; }
+static uint64_t *flag_peer(pmg_dist d, int side, int idx) { return (side == 0 ? d->lo : d->hi) >= 0 ? (uint64_t *)d->peer_block[side] + idx : NULL; }
+
+/* on `st`: tell both neighbours that my colour-c planes of round round[c] are in their blocks (my low plane sits in
+   the low neighbour's HIGH slot and vice versa) */
+static pmg_status ipc_signal_color(pmg_dist d, int c, hipStream_t st)
 {
-  for (int side = 0; side < 2; ++side) {
-    const int nb = side == 0 ? d->lo : d->hi;
-    if (nb < 0) continue;
-    uint64_t spins = 0;
-    while (atomic_load_explicit(&d->shm->seq[nb][c], memory_order_acquire) < d->round[c]) { /* the record has been ISSUED */
-      if (++spins > 4000000000ull) PMG_FAIL(PMG_ERR_LIB, "rank %d: neighbour %d never issued push %llu of colour %d", d->rank, nb, (unsigned long long)d->round[c], c);
-    }
-    PMG_HIP(hipStreamWaitEvent(s, d->peer_ev[side][c], 0));
-  }
+  PMG_KERNEL(pmgk_flag_signal(flag_peer(d, 0, c * 2 + 1), d->round[c], flag_peer(d, 1, c * 2 + 0), d->round[c], st));
   return PMG_SUCCESS;
 }
 
+/* on `st`: wait until both neighbours' colour-c planes of round round[c] have landed in my block */
+static pmg_status ipc_wait_color(pmg_dist d, int c, hipStream_t st)
+{
+  PMG_KERNEL(pmgk_flag_wait(d->lo >= 0 ? flag_mine(d, c * 2 + 0) : NULL, d->round[c], d->hi >= 0 ? flag_mine(d, c * 2 + 1) : NULL, d->round[c], d->err_dev, st));
+  return PMG_SUCCESS;
+}
+
+/* a flag wait of an EARLIER round gave up (lost neighbour): fail the next call instead of computing on */
+static pmg_status ipc_check(pmg_dist d)
+{
+  PMG_CHECK(*(volatile unsigned *)d->err_dev == 0, PMG_ERR_LIB, "rank %d: a halo flag never arrived (neighbour lost?)", d->rank);
+  return PMG_SUCCESS;
+}
+
+/* Two in-order streams per rank: the caller's stream s sweeps the INTERIOR planes of a colour, the face stream
+   f = cs runs  [wait for the neighbours' planes of the other colour] -> [face planes: read them from my block, store
+   the new planes into y and straight into the neighbours' blocks] -> [raise the neighbours' flags]  beside it; two
+   local events per colour tie them together (the faces of colour c read the interior of colour 1-c and vice versa).
+   The flag traffic and the small face kernel are hidden behind the interior sweep. */
 static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, hipStream_t s)
 {
   const int32_t nz = d->nz;
+  hipStream_t   f  = d->cs;
+  int64_t       own, ghost, n;
+  PMG_CALL(ipc_check(d));
   PMG_HIP(hipEventRecord(d->evS, s));
-  PMG_CALL(ipc_push_copy(d, 0, y, d->evS)); /* the receive blocks hold nothing of this y yet */
-  PMG_CALL(ipc_push_copy(d, 1, y, d->evS));
-  uint64_t ctr = counter0;
+  PMG_HIP(hipStreamWaitEvent(f, d->evS, 0));
+  for (int c = 0; c < 2; ++c) { /* the receive blocks hold nothing of this y yet: copy my boundary planes over */
+    d->round[c] += 1;
+    for (int side = 0; side < 2; ++side) {
+      if ((side == 0 ? d->lo : d->hi) < 0) continue;
+      PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
+      PMG_HIP(hipMemcpyAsync(d->peer_recv[side] + (int64_t)(c * 2 + (1 - side)) * d->plane, y + own, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, f));
+    }
+    PMG_CALL(ipc_signal_color(d, c, f));
+  }
+  int      have_interior = 0; /* an interior sweep has been queued on s since the call began */
+  uint64_t ctr           = counter0;
   for (int32_t it = 0; it < its; ++it) {
     const int ndir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
     for (int q = 0; q < ndir; ++q) {
       const int dir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? (q == 0 ? PMG_SOR_FORWARD_SWEEP : PMG_SOR_BACKWARD_SWEEP) : sweep_type;
       for (int cc = 0; cc < 2; ++cc) {
         const int c = dir == PMG_SOR_FORWARD_SWEEP ? cc : 1 - cc;
-        PMG_CALL(ipc_wait(d, 1 - c, s));              /* colour c reads colour 1-c across the slab faces */
-        PMG_HIP(hipStreamWaitEvent(s, d->evP[c], 0)); /* (first sweep) the initial copy has read the planes I am about to rewrite */
-        /* face planes: read the neighbours' colour 1-c planes from my receive block, write the new colour-c planes
-           into y AND straight into the neighbours' receive blocks (peer stores over xGMI) */
+        /* face stream */
+        if (have_interior) PMG_HIP(hipStreamWaitEvent(f, d->evT[(d->nthrottle - 1) % PMG_IPC_WINDOW], 0)); /* the last interior sweep (the other colour) */
+        PMG_CALL(ipc_wait_color(d, 1 - c, f));
         pmgk_grid_halo h;
         h.glo = d->lo >= 0 ? d->recv + (int64_t)((1 - c) * 2 + 0) * d->plane : NULL;
         h.ghi = d->hi >= 0 ? d->recv + (int64_t)((1 - c) * 2 + 1) * d->plane : NULL;
         h.plo = d->lo >= 0 ? d->peer_recv[0] + (int64_t)(c * 2 + 1) * d->plane : NULL;
         h.phi = d->hi >= 0 ? d->peer_recv[1] + (int64_t)(c * 2 + 0) * d->plane : NULL;
-        PMG_CALL(pmg_grid_sweep_color_faces_cvec(d->g, c, 1, scaled, seed, ctr, &h, b, y, s));
-        /* "my push of colour c has landed" = completion of the face kernel.  Recording an INTERPROCESS event costs a
-           stream-write packet and a ~30 us bubble on the stream it is recorded on (measured), so it goes to the comm
-           stream behind a cheap local event and the compute stream runs straight on into the interior planes. */
-        PMG_HIP(hipEventRecord(d->evP[c], s));
-        PMG_HIP(hipStreamWaitEvent(d->cs, d->evP[c], 0));
-        PMG_HIP(hipEventRecord(d->ipc_ev[c], d->cs));
+        PMG_CALL(pmg_grid_sweep_color_faces_cvec(d->g, c, 1, scaled, seed, ctr, &h, b, y, f));
         d->round[c] += 1;
-        atomic_store_explicit(&d->shm->seq[d->rank][c], d->round[c], memory_order_release);
-        if (nz > 2) PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, 1, nz - 2, 1, scaled, seed, ctr, b, y, s));
+        PMG_CALL(ipc_signal_color(d, c, f));
+        PMG_HIP(hipEventRecord(d->evF[c], f));
+        /* compute stream: the interior of colour c reads the face planes of colour 1-c */
+        if (nz > 2) {
+          PMG_HIP(hipStreamWaitEvent(s, d->evF[1 - c], 0));
+          PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, 1, nz - 2, 1, scaled, seed, ctr, b, y, s));
+          const int slot = (int)(d->nthrottle % PMG_IPC_WINDOW);
+          if (d->nthrottle >= PMG_IPC_WINDOW) PMG_HIP(hipEventSynchronize(d->evT[slot])); /* bounded host run-ahead */
+          PMG_HIP(hipEventRecord(d->evT[slot], s));
+          d->nthrottle += 1;
+          have_interior = 1;
+        }
       }
       ++ctr;
     }
   }
-  /* leave y self-contained: bring the latest neighbour planes into its own ghost planes */
+  /* leave y self-contained: bring the latest neighbour planes into its own ghost planes (on the face stream), then
+     let the caller's stream see everything */
+  if (have_interior) PMG_HIP(hipStreamWaitEvent(f, d->evT[(d->nthrottle - 1) % PMG_IPC_WINDOW], 0));
   for (int c = 0; c < 2; ++c) {
-    PMG_CALL(ipc_wait(d, c, s));
-    int64_t own, ghost, n;
+    PMG_CALL(ipc_wait_color(d, c, f));
     for (int side = 0; side < 2; ++side) {
       if ((side == 0 ? d->lo : d->hi) < 0) continue;
       PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
-      PMG_HIP(hipMemcpyAsync(y + ghost, d->recv + (int64_t)(c * 2 + side) * d->plane, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+      PMG_HIP(hipMemcpyAsync(y + ghost, d->recv + (int64_t)(c * 2 + side) * d->plane, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, f));
     }
   }
+  PMG_HIP(hipEventRecord(d->evF[0], f));
+  PMG_HIP(hipStreamWaitEvent(s, d->evF[0], 0));
   if (counter_out) *counter_out = ctr;
   return PMG_SUCCESS;
 }
@@ -391,25 +393,18 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
   pmg_dist d = *dp;
   if (d->transport == 1) {
     (void)hipDeviceSynchronize();
-    for (int side = 0; side < 2 && !d->loopback; ++side) {
-      if (d->peer_recv[side]) (void)hipIpcCloseMemHandle(d->peer_recv[side]);
-      if (d->peer_grecv[side]) (void)hipIpcCloseMemHandle(d->peer_grecv[side]);
-      for (int c = 0; c < 2; ++c) {
-        if (d->peer_ev[side][c]) (void)hipEventDestroy(d->peer_ev[side][c]);
-        if (d->peer_gev[side][c]) (void)hipEventDestroy(d->peer_gev[side][c]);
-      }
-    }
-    for (int q = 0; q < 2; ++q) {
-      if (d->gev[q]) (void)hipEventDestroy(d->gev[q]);
-      if (d->gevL[q]) (void)hipEventDestroy(d->gevL[q]);
-    }
-    if (d->grecv) (void)hipFree(d->grecv);
+    for (int side = 0; side < 2 && !d->loopback; ++side)
+      if (d->peer_block[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
     for (int c = 0; c < 2; ++c) {
-      if (d->ipc_ev[c]) (void)hipEventDestroy(d->ipc_ev[c]);
       if (d->evP[c]) (void)hipEventDestroy(d->evP[c]);
+      if (d->evW[c]) (void)hipEventDestroy(d->evW[c]);
     }
-    if (d->recv) (void)hipFree(d->recv);
-    if (d->shm) munmap(d->shm, sizeof(pmg_ipc_shm));
+    for (int q = 0; q < PMG_IPC_WINDOW; ++q)
+      if (d->evT[q]) (void)hipEventDestroy(d->evT[q]);
+    for (int c = 0; c < 2; ++c)
+      if (d->evF[c]) (void)hipEventDestroy(d->evF[c]);
+    if (d->err_dev) (void)hipHostFree(d->err_dev);
+    if (d->block) (void)hipFree(d->block);
   }
   if (d->comm && d->api.CommDestroy) d->api.CommDestroy(d->comm);
   for (int c = 0; c < 2; ++c) {
@@ -431,9 +426,10 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
    must agree (sender's n_send = receiver's n_recv), sides without a neighbour are skipped, zero-length segments are
    allowed.  Every rank must make the same sequence of calls (the IPC transport counts rounds).
    RCCL: one grouped ncclSend/ncclRecv on the communication stream, between two event edges.
-   IPC : the segments are copied straight into the neighbour's generic receive block (two parities, so that round
-         r + 2 can be pushed while the neighbour still reads round r: it cannot have started r + 1's push, which I
-         wait for before r + 2, without having consumed r -- its streams are in order), then copied out locally. */
+   IPC : the segments are copied straight into the neighbour's generic message slots (two parities, so that round
+         r + 2 may be pushed while the neighbour still holds round r: I push r + 2 only after its round r + 1 arrived,
+         which it sent after copying round r out -- its stream is in order), its flag word is raised to the round
+         number, my stream waits for my flag word and copies the message out. */
 pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo, const int64_t *nsend_lo, double *const *recv_lo, const int64_t *nrecv_lo, const double *const *send_hi, const int64_t *nsend_hi, double *const *recv_hi, const int64_t *nrecv_hi, void *stream)
 {
   PMG_CHECK(d, PMG_ERR_ARG_NULL, "null dist object");
@@ -444,9 +440,9 @@ pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo,
   double *const       *rcv[2] = {recv_lo, recv_hi};
   const int64_t       *ns[2] = {nsend_lo, nsend_hi}, *nr[2] = {nrecv_lo, nrecv_hi};
   const int            nb[2] = {d->lo, d->hi};
-  PMG_HIP(hipEventRecord(d->evG, s));
-  PMG_HIP(hipStreamWaitEvent(d->cs, d->evG, 0));
   if (d->transport == 0) {
+    PMG_HIP(hipEventRecord(d->evG, s));
+    PMG_HIP(hipStreamWaitEvent(d->cs, d->evG, 0));
     PMG_NCCL(d, d->api.GroupStart());
     for (int side = 0; side < 2; ++side) {
       if (nb[side] < 0) continue;
@@ -460,34 +456,31 @@ pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo,
     PMG_HIP(hipStreamWaitEvent(s, d->evGx, 0));
     return PMG_SUCCESS;
   }
+  /* IPC: everything on the caller's stream -- push my segments into the neighbours' slots of parity p, raise their
+     flags, wait for mine, copy out */
+  PMG_CALL(ipc_check(d));
   const int p = (int)(d->ground & 1);
+  d->ground += 1;
   for (int side = 0; side < 2; ++side) {
     if (nb[side] < 0) continue;
     int64_t off = 0;
     for (int q = 0; q < nseg; ++q) {
       PMG_CHECK(off + ns[side][q] <= d->gcap, PMG_ERR_ARG_SIZ, "exchange of %lld doubles exceeds the receive block (%lld)", (long long)(off + ns[side][q]), (long long)d->gcap);
-      if (ns[side][q] > 0) PMG_HIP(hipMemcpyAsync(d->peer_grecv[side] + (int64_t)(p * 2 + (1 - side)) * d->gcap + off, snd[side][q], sizeof(double) * (size_t)ns[side][q], hipMemcpyDeviceToDevice, d->cs));
+      if (ns[side][q] > 0) PMG_HIP(hipMemcpyAsync(d->peer_grecv[side] + (int64_t)(p * 2 + (1 - side)) * d->gcap + off, snd[side][q], sizeof(double) * (size_t)ns[side][q], hipMemcpyDeviceToDevice, s));
       off += ns[side][q];
     }
   }
-  PMG_HIP(hipEventRecord(d->gev[p], d->cs));
-  PMG_HIP(hipEventRecord(d->gevL[p], d->cs));
-  d->ground += 1;
-  atomic_store_explicit(&d->shm->gseq[d->rank], d->ground, memory_order_release);
+  PMG_KERNEL(pmgk_flag_signal(flag_peer(d, 0, 4 + 1), d->ground, flag_peer(d, 1, 4 + 0), d->ground, s));
+  PMG_KERNEL(pmgk_flag_wait(nb[0] >= 0 ? flag_mine(d, 4 + 0) : NULL, d->ground, nb[1] >= 0 ? flag_mine(d, 4 + 1) : NULL, d->ground, d->err_dev, s));
   for (int side = 0; side < 2; ++side) {
     if (nb[side] < 0) continue;
-    uint64_t spins = 0;
-    while (atomic_load_explicit(&d->shm->gseq[nb[side]], memory_order_acquire) < d->ground) {
-      if (++spins > 4000000000ull) PMG_FAIL(PMG_ERR_LIB, "rank %d: neighbour %d never issued exchange %llu", d->rank, nb[side], (unsigned long long)d->ground);
-    }
-    PMG_HIP(hipStreamWaitEvent(s, d->peer_gev[side][p], 0));
     int64_t off = 0;
     for (int q = 0; q < nseg; ++q) {
       if (nr[side][q] > 0) PMG_HIP(hipMemcpyAsync(rcv[side][q], d->grecv + (int64_t)(p * 2 + side) * d->gcap + off, sizeof(double) * (size_t)nr[side][q], hipMemcpyDeviceToDevice, s));
       off += nr[side][q];
     }
   }
-  return PMG_SUCCESS;
+  return ipc_throttle(d, s);
 }
 
 /* every rank ends up with all blocks: block r = counts[r] doubles at buf + offsets[r], rank r owns block r.

@@ -118,6 +118,10 @@ int pmgk_lrc_axpy_cols(int64_t n, int k, const double *M, int64_t ld, const doub
 int pmgk_lrc_gemm_small(int64_t n, int k, const double *Cm, int64_t ld, const double *Sb, double *Bb, void *stream);
 int pmgk_lrc_mul(int k, const double *a, const double *b, double *out, void *stream);
 int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);
+/* flag words of the "ipc" halo transport: raise up to two words (system-scope release) / wait until up to two words have
+   reached their values (one wave, sleeps between polls, *err = 1 after ~10 s); null pointers are skipped */
+int pmgk_flag_signal(uint64_t *p0, uint64_t v0, uint64_t *p1, uint64_t v1, void *stream);
+int pmgk_flag_wait(const uint64_t *f0, uint64_t v0, const uint64_t *f1, uint64_t v1, unsigned *err, void *stream);
 int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream);
 
 #ifdef __cplusplus
