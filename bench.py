@@ -208,6 +208,26 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     finite = bool(torch.isfinite(y).all().item())
+    # multi-GPU only, outside the timed region: rank 0 repeats the whole chain on ITS device alone and compares its slab
+    # bit for bit (the noise depends on global indices only, so the distributed chain must reproduce it exactly)
+    halo_check = None
+    if world > 1 and os.environ.get("PMG_BENCH_NO_HALO_CHECK") != "1":
+        try:
+            if rank == 0:
+                from parmgmc_amd import GridMCSOR
+
+                one = GridMCSOR(n, n, n, 10.0)
+                one.set_omega(args.omega)
+                ob = one.to_cvec(torch.ones(one.n, dtype=torch.float64, device="cuda"))
+                oy = one.new_cvec()
+                one.sample_cvec(ob, oy, args.warmup + args.steps, seed, 0, True)
+                mine = g.from_cvec(y)
+                ref = one.from_cvec(oy)[: mine.numel()]
+                halo_check = "bit-identical to the single-device chain (rank 0's slab)" if torch.equal(mine, ref) else f"MISMATCH vs the single-device chain: max abs diff {float((mine - ref).abs().max()):.3e}"
+                del one, ob, oy, mine, ref
+                torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            halo_check = f"not run: {type(e).__name__}: {e}"
 
     if rank == 0:
         N_total = n * n * n
@@ -234,6 +254,8 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None, "kernel": "grid_color_sweep_kernel", "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_us": t_launch * 1e6, "note": "24 B/unknown/sweep (read y, write y, read b once; SURVEY 8(d)) x N/2 unknowns per colour launch; duration = HIP-event time of the timed region / launches"},
             "finite": finite,
         }
+        if halo_check is not None:
+            out["halo_check"] = halo_check
     else:
         out = None
     # ---- secondary lines: never allowed to cost the headline line -------------------------------------------------

@@ -153,9 +153,9 @@ class RcclSlabDriver:
 
 
 class IpcSlabDriver(RcclSlabDriver):
-    """The C sample loop of pmg_dist.c with the "ipc" transport: boundary planes are copied device-to-device straight
-    into the neighbour's receive block (hipIpc memory, interprocess events); torch.distributed only carries the
-    bootstrap (16-byte job token, all-gather of the handle blobs, one barrier)."""
+    """The C sample loop of pmg_dist.c with the "ipc" transport: boundary planes are stored device-to-device straight
+    into the neighbour's receive block (hipIpc memory) and announced by flag words; torch.distributed only carries
+    the bootstrap (all-gather of the handle blobs, one barrier)."""
 
     def __init__(self, grid, rank: int, world: int, group=None, loopback: bool = False):
         import ctypes as C
@@ -168,7 +168,6 @@ class IpcSlabDriver(RcclSlabDriver):
         if loopback:
             check(lib.pmg_dist_create_ipc(grid._h, 0, 1, C.create_string_buffer(os.urandom(16), 16), C.byref(self._h)))
             check(lib.pmg_dist_ipc_connect_loopback(self._h))
-            check(lib.pmg_dist_ipc_unlink(self._h))
             return
         import torch.distributed as dist
 
@@ -185,8 +184,31 @@ class IpcSlabDriver(RcclSlabDriver):
         hi = C.create_string_buffer(blobs[rank + 1], nb.value) if rank < world - 1 else None
         check(lib.pmg_dist_ipc_connect(self._h, lo, hi))
         dist.barrier(group=group)
-        if rank == 0:
-            check(lib.pmg_dist_ipc_unlink(self._h))
+        self._selftest(rank, world)
+
+    def _selftest(self, rank, world):
+        """One round trip of a known pattern with both z-neighbours (peer copies into their blocks, flag words, copy
+        out): if peer access or the flags do not work on this machine the constructor fails -- on every rank, the
+        wait gives up after ~10 s -- and DistGridSampler moves on to the next transport."""
+        import ctypes as C
+
+        import torch
+
+        from .capi import check, lib
+        from .wrappers import _ptr, _stream
+
+        n = 4096
+        send = torch.full((2, n), float(rank + 1), dtype=torch.float64, device="cuda") + torch.arange(n, dtype=torch.float64, device="cuda") / n
+        recv = torch.zeros((2, n), dtype=torch.float64, device="cuda")
+        P, I64 = C.c_void_p * 1, C.c_int64 * 1
+        nn = I64(n)
+        check(lib.pmg_dist_exchange(self._h, 1, P(_ptr(send[0])), nn, P(_ptr(recv[0])), nn, P(_ptr(send[1])), nn, P(_ptr(recv[1])), nn, _stream()))
+        torch.cuda.synchronize()
+        frac = torch.arange(n, dtype=torch.float64, device="cuda") / n
+        if rank > 0 and not torch.equal(recv[0], float(rank) + frac):
+            raise RuntimeError("ipc halo self-test: wrong data from the low neighbour")
+        if rank < world - 1 and not torch.equal(recv[1], float(rank + 2) + frac):
+            raise RuntimeError("ipc halo self-test: wrong data from the high neighbour")
 
 
 class DistGridSampler:
