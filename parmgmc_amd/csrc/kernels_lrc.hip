@@ -59,6 +59,61 @@ __global__ __launch_bounds__(256) void lrc_gemm_small_kernel(int64_t n, int k, c
   }
 }
 
+// ---- row-compact form: the observation vectors are supported on small balls (reference src/obs.c:39-50), and one
+// sweep from a zero guess spreads that support by one layer per colour only, so B, Bb are stored for the ns << N
+// support rows: Mc[q + ns*c] = M[rows[q] + ld*c].  8 ns k bytes per pass instead of 8 N k.
+__global__ __launch_bounds__(256) void lrc_mark_rows_kernel(int64_t n, int k, const double *__restrict__ A0, const double *__restrict__ A1, const double *__restrict__ A2, int64_t ld, unsigned char *__restrict__ mask)
+{
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  bool nz = false;
+  for (int c = 0; c < k; ++c) nz = nz || A0[r + ld * c] != 0.0 || A1[r + ld * c] != 0.0 || A2[r + ld * c] != 0.0;
+  mask[r] = nz ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void lrc_gather_rows_kernel(int64_t ns, int k, const double *__restrict__ M, int64_t ld, const int64_t *__restrict__ rows, double *__restrict__ Mc)
+{
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= ns) return;
+  const int64_t r = rows[q];
+  for (int c = 0; c < k; ++c) Mc[q + ns * c] = M[r + ld * c];
+}
+
+__global__ __launch_bounds__(256) void lrc_btx_rows_partial_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, const double *__restrict__ y, double *__restrict__ partial)
+{
+  __shared__ double red[4];
+  const int64_t q0 = (int64_t)blockIdx.x * 4096;
+  for (int c = 0; c < k; ++c) {
+    double s = 0.0;
+    for (int64_t q = q0 + threadIdx.x; q < q0 + 4096 && q < ns; q += 256) s = fma(Mc[q + ns * c], y[rows[q]], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * k + c] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+}
+
+// v[rows[q]] = v[rows[q]] + sign * sum_c Mc[q + ns*c] * coef[c]; save != null keeps the old value (to undo it exactly)
+__global__ __launch_bounds__(256) void lrc_axpy_rows_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, const double *__restrict__ coef, double sign, double *__restrict__ v, double *__restrict__ save)
+{
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= ns) return;
+  double s = 0.0;
+  for (int c = 0; c < k; ++c) s = fma(Mc[q + ns * c], coef[c], s);
+  const int64_t r = rows[q];
+  const double  o = v[r];
+  if (save) save[q] = o;
+  v[r] = o + sign * s;
+}
+
+__global__ __launch_bounds__(256) void lrc_scatter_rows_kernel(int64_t ns, const int64_t *__restrict__ rows, const double *__restrict__ save, double *__restrict__ v)
+{
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < ns) v[rows[q]] = save[q];
+}
+
 __global__ void lrc_mul_kernel(int k, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
 {
   const int c = threadIdx.x;
@@ -97,5 +152,42 @@ extern "C" int pmgk_lrc_gemm_small(int64_t n, int k, const double *Cm, int64_t l
 extern "C" int pmgk_lrc_mul(int k, const double *a, const double *b, double *out, void *stream)
 {
   hipLaunchKernelGGL(lrc_mul_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, a, b, out);
+  return launch_status();
+}
+
+extern "C" int pmgk_lrc_mark_rows(int64_t n, int k, const double *A0, const double *A1, const double *A2, int64_t ld, unsigned char *mask, void *stream)
+{
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(lrc_mark_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, k, A0, A1, A2, ld, mask);
+  return launch_status();
+}
+
+extern "C" int pmgk_lrc_gather_rows(int64_t ns, int k, const double *M, int64_t ld, const int64_t *rows, double *Mc, void *stream)
+{
+  if (ns <= 0) return 0;
+  hipLaunchKernelGGL(lrc_gather_rows_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ns, k, M, ld, rows, Mc);
+  return launch_status();
+}
+
+extern "C" int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *y, double *partial, const double *scale, double *out, void *stream)
+{
+  if (ns <= 0 || k <= 0) return 0;
+  const int nb = pmgk_lrc_nblocks(ns);
+  hipLaunchKernelGGL(lrc_btx_rows_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, y, partial);
+  hipLaunchKernelGGL(lrc_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nb, k, partial, scale, out);
+  return launch_status();
+}
+
+extern "C" int pmgk_lrc_axpy_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *coef, double sign, double *v, double *save, void *stream)
+{
+  if (ns <= 0) return 0;
+  hipLaunchKernelGGL(lrc_axpy_rows_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, coef, sign, v, save);
+  return launch_status();
+}
+
+extern "C" int pmgk_lrc_scatter_rows(int64_t ns, const int64_t *rows, const double *save, double *v, void *stream)
+{
+  if (ns <= 0) return 0;
+  hipLaunchKernelGGL(lrc_scatter_rows_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ns, rows, save, v);
   return launch_status();
 }

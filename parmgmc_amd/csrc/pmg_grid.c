@@ -180,6 +180,7 @@ static pmg_status pmg_grid_one_sweep(pmg_grid g, int dir, int noisy, int scaled,
   const int c0 = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
   PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, 1, NULL, b, y, stream));
   PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, 1, NULL, b, y, stream));
+  if (g->lrc && noisy) PMG_CALL(pmg_lrc_rhs_done(g->lrc, stream));
   if (g->lrc) PMG_CALL(pmg_lrc_post(g->lrc, dir, y, stream));
   return PMG_SUCCESS;
 }

@@ -48,6 +48,7 @@ typedef struct pmg_lrc_s *pmg_lrc;
 typedef pmg_status (*pmg_det_sweep_fn)(void *ctx, int dir, const double *b_lay, double *y_lay, void *stream);
 pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const double *B_nat_host, const int64_t *pos, const double *S_host, pmg_det_sweep_fn det, void *ctx);
 pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t counter, const double **beff, void *stream);
+pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream); /* after the sweep that used the vector pmg_lrc_rhs returned */
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream);
 void       pmg_lrc_destroy(pmg_lrc *l);

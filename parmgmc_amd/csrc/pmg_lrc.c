@@ -13,6 +13,7 @@
  */
 #include "pmg_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 struct pmg_lrc_s {
   int      k;
@@ -20,6 +21,13 @@ struct pmg_lrc_s {
   double  *B, *Bb[2]; /* device, ld x k column-major; Bb[0] forward, Bb[1] backward */
   double  *S, *sqrtS; /* device, k */
   double  *wk, *eta, *partial, *beff, *col; /* device work space */
+  /* row-compact form (ns > 0): only the support rows of B, Bb are kept -- ball observations touch << N rows
+     (src/obs.c:39-50) and one sweep from a zero guess widens the support by a layer per colour only */
+  int64_t  ns;
+  int64_t *rows;             /* device, ns layout positions, ascending */
+  double  *Bc, *Bbc[2];      /* device, ns x k column-major */
+  double  *saved;            /* device, ns: the right-hand side entries under the noise term */
+  double  *b_mod;            /* the vector whose support rows currently carry the noise term */
 };
 
 void pmg_lrc_destroy(pmg_lrc *p)
@@ -36,6 +44,11 @@ void pmg_lrc_destroy(pmg_lrc *p)
   pmg_dev_free(l->partial);
   pmg_dev_free(l->beff);
   pmg_dev_free(l->col);
+  pmg_dev_free(l->rows);
+  pmg_dev_free(l->Bc);
+  pmg_dev_free(l->Bbc[0]);
+  pmg_dev_free(l->Bbc[1]);
+  pmg_dev_free(l->saved);
   free(l);
   *p = NULL;
 }
@@ -75,6 +88,49 @@ int pmg_invert_small(int k, double *a, double *inv)
       }
   }
   return 0;
+}
+
+/* switch to the row-compact form when the joint support of B, Bb[0], Bb[1] is at most a quarter of the rows */
+static pmg_status lrc_compact(pmg_lrc l)
+{
+  unsigned char *mask_dev = NULL, *mask = (unsigned char *)malloc((size_t)l->ld);
+  PMG_CHECK(mask, PMG_ERR_MEM, "out of host memory");
+  pmg_status st = pmg_dev_alloc((void **)&mask_dev, (size_t)l->ld);
+  if (!st && pmgk_lrc_mark_rows(l->ld, l->k, l->B, l->Bb[0], l->Bb[1], l->ld, mask_dev, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
+  if (!st && hipMemcpy(mask, mask_dev, (size_t)l->ld, hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
+  pmg_dev_free(mask_dev);
+  int64_t ns = 0;
+  for (int64_t r = 0; r < l->ld && !st; ++r) ns += mask[r];
+  if (st || ns == 0 || ns > l->ld / 4) {
+    free(mask);
+    return st;
+  }
+  int64_t *rows = (int64_t *)malloc(sizeof(int64_t) * (size_t)ns);
+  if (!rows) {
+    free(mask);
+    PMG_FAIL(PMG_ERR_MEM, "out of host memory");
+  }
+  for (int64_t r = 0, q = 0; r < l->ld; ++r)
+    if (mask[r]) rows[q++] = r;
+  free(mask);
+  st = pmg_dev_upload((void **)&l->rows, rows, sizeof(int64_t) * (size_t)ns);
+  free(rows);
+  const size_t cb = sizeof(double) * (size_t)ns * (size_t)l->k;
+  if (!st) st = pmg_dev_alloc((void **)&l->Bc, cb);
+  if (!st) st = pmg_dev_alloc((void **)&l->Bbc[0], cb);
+  if (!st) st = pmg_dev_alloc((void **)&l->Bbc[1], cb);
+  if (!st) st = pmg_dev_alloc((void **)&l->saved, sizeof(double) * (size_t)ns);
+  if (!st && (pmgk_lrc_gather_rows(ns, l->k, l->B, l->ld, l->rows, l->Bc, NULL) || pmgk_lrc_gather_rows(ns, l->k, l->Bb[0], l->ld, l->rows, l->Bbc[0], NULL) || pmgk_lrc_gather_rows(ns, l->k, l->Bb[1], l->ld, l->rows, l->Bbc[1], NULL))) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
+  if (!st && hipDeviceSynchronize() != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device error while compacting the low-rank factors");
+  if (st) return st;
+  l->ns = ns;
+  pmg_dev_free(l->B); /* the dense copies are not needed any more */
+  pmg_dev_free(l->Bb[0]);
+  pmg_dev_free(l->Bb[1]);
+  pmg_dev_free(l->col);
+  pmg_dev_free(l->beff);
+  l->B = l->Bb[0] = l->Bb[1] = l->col = l->beff = NULL;
+  return PMG_SUCCESS;
 }
 
 pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const double *B_nat_host, const int64_t *pos, const double *S_host, pmg_det_sweep_fn det, void *ctx)
@@ -130,6 +186,7 @@ pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const d
   free(T);
   free(Sb);
   pmg_dev_free(Sb_dev);
+  if (!st && !getenv("PMG_LRC_DENSE")) st = lrc_compact(l);
   if (st) {
     pmg_lrc_destroy(&l);
     return st;
@@ -138,13 +195,32 @@ pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const d
   return PMG_SUCCESS;
 }
 
-/* b_eff = b + B (sqrt(S) o eta), eta = row-stream normals of (seed + tag, counter); returns the device vector */
+/* b_eff = b + B (sqrt(S) o eta), eta = row-stream normals of (seed + tag, counter); returns the device vector to
+   sweep with.  Row-compact form: the noise term is added to the support rows of b IN PLACE (old values saved) and
+   b itself is returned -- pmg_lrc_rhs_done puts the saved values back after the sweep, bit for bit. */
 pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t counter, const double **beff, void *stream)
 {
   PMG_KERNEL(pmgk_fill_normal_rows(l->k, seed + 0x632BE59BD9B4E019ull, counter, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w) */
   PMG_KERNEL(pmgk_lrc_mul(l->k, l->eta, l->sqrtS, l->eta, stream));                               /* VecPointwiseMult(w, w, sqrtS)   */
+  if (l->ns) {
+    PMG_CHECK(!l->b_mod, PMG_ERR_ARG_WRONGSTATE, "pmg_lrc_rhs_done missing");
+    l->b_mod = (double *)b_lay;
+    PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->eta, 1.0, l->b_mod, l->saved, stream)); /* MatMultAdd(B, w, rhs, rhs) */
+    *beff = b_lay;
+    return PMG_SUCCESS;
+  }
   PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->B, l->ld, l->eta, 1.0, b_lay, l->beff, stream));  /* MatMultAdd(B, w, rhs, rhs)      */
   *beff = l->beff;
+  return PMG_SUCCESS;
+}
+
+/* after the sweep that used the vector of pmg_lrc_rhs */
+pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream)
+{
+  if (l->ns && l->b_mod) {
+    PMG_KERNEL(pmgk_lrc_scatter_rows(l->ns, l->rows, l->saved, l->b_mod, stream));
+    l->b_mod = NULL;
+  }
   return PMG_SUCCESS;
 }
 
@@ -152,6 +228,11 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
    residual operator is pointed at for MATLRC levels, src/pc_gamgmc.c:186-194) */
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream)
 {
+  if (l->ns) {
+    PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, x_lay, l->partial, l->S, l->wk, stream));
+    PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->wk, -1.0, r_lay, NULL, stream));
+    return PMG_SUCCESS;
+  }
   PMG_KERNEL(pmgk_lrc_btx(l->ld, l->k, l->B, l->ld, x_lay, l->partial, l->S, l->wk, stream));
   PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->B, l->ld, l->wk, -1.0, r_lay, r_lay, stream));
   return PMG_SUCCESS;
@@ -160,7 +241,13 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
 /* y -= Bb_dir (B^T y), src/mc_sor.c:101-112 */
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
 {
+  const int d = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
+  if (l->ns) {
+    PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, y_lay, l->partial, NULL, l->wk, stream));
+    PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, NULL, stream));
+    return PMG_SUCCESS;
+  }
   PMG_KERNEL(pmgk_lrc_btx(l->ld, l->k, l->B, l->ld, y_lay, l->partial, NULL, l->wk, stream));
-  PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->Bb[dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1], l->ld, l->wk, -1.0, y_lay, y_lay, stream));
+  PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->Bb[d], l->ld, l->wk, -1.0, y_lay, y_lay, stream));
   return PMG_SUCCESS;
 }

@@ -378,6 +378,7 @@ static pmg_status mcsor_sweep_lrc(pmg_mcsor mc, int dir, int noisy, int scaled, 
   const double *rhs = b_p;
   if (mc->lrc && noisy) PMG_CALL(pmg_lrc_rhs(mc->lrc, b_p, seed, sweep, &rhs, stream));
   PMG_CALL(mcsor_one_sweep(mc, dir, noisy, scaled, seed, sweep, rhs, y_p, stream));
+  if (mc->lrc && noisy) PMG_CALL(pmg_lrc_rhs_done(mc->lrc, stream));
   if (mc->lrc) PMG_CALL(pmg_lrc_post(mc->lrc, dir, y_p, stream));
   return PMG_SUCCESS;
 }

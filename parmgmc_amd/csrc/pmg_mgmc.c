@@ -1105,6 +1105,7 @@ static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, 
       } else {
         PMG_KERNEL(pmgk_st27_sweep(&S, backward, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
       }
+      if (Lv->lrc) PMG_CALL(pmg_lrc_rhs_done(Lv->lrc, stream));
       if (Lv->lrc) PMG_CALL(pmg_lrc_post(Lv->lrc, backward ? PMG_SOR_BACKWARD_SWEEP : PMG_SOR_FORWARD_SWEEP, Lv->x, stream)); /* src/mc_sor.c:101-112 */
     }
   }

@@ -341,3 +341,45 @@ def test_ex4_mgmc_posterior_mean_on_device():
     mg.sample(bd, y, 20000, seed=5, counter0=ctr, callback=lambda it, yy: mean.mul_(it / (it + 1.0)).add_(yy, alpha=1.0 / (it + 1)))
     ex = np.linalg.solve(A.dense() + B @ np.diag(S) @ B.T, b)
     assert np.linalg.norm(host(mean) - ex) / np.linalg.norm(ex) < 0.14
+
+
+def ball_matrix(grid, centres, radii):
+    """ball-indicator observation vectors on the unit cube grid (reference src/obs.c:39-50): supported on << N rows"""
+    nx, ny, nz = grid
+    X, Y, Z = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), np.linspace(0, 1, nz) if nz > 1 else np.zeros(1), indexing="ij")
+    pts = np.stack([X.ravel(order="F"), Y.ravel(order="F"), Z.ravel(order="F")], 1)  # natural order, x fastest
+    B = np.zeros((nx * ny * nz, len(radii)))
+    for c, (ctr, r) in enumerate(zip(centres, radii)):
+        inside = ((pts - np.asarray(ctr)) ** 2).sum(1) < r * r
+        B[inside, c] = 1.0 / max(1, inside.sum())
+    return B
+
+
+@pytest.mark.gpu
+def test_device_mgmc_lrc_row_compact_form(monkeypatch):
+    """ball observations are stored for their support rows only; the chain must agree with the dense
+    storage to rounding, sample by sample, and with the oracle"""
+    import torch
+
+    from parmgmc_amd import MGMC
+
+    grid, kappa, levels = (33, 33, 17), 2.0, 3
+    n = int(np.prod(grid))
+    B = ball_matrix(grid, [(0.3, 0.3, 0.4), (0.7, 0.6, 0.5), (0.5, 0.2, 0.8)], [0.12, 0.15, 0.1])
+    assert 0 < (np.abs(B).sum(1) > 0).mean() < 0.05
+    S = np.array([50.0, 80.0, 30.0])
+    rng = np.random.default_rng(2)
+    b, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    out = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("PMG_LRC_DENSE", "1")
+        mg = MGMC(*grid, kappa, levels)
+        mg.set_smoother(True, 1.1, O.SOR_SYMMETRIC, 1)
+        mg.set_lowrank(B, S)
+        mg.setup()
+        bd, yd = dev(b), dev(y0)
+        mg.sample(bd, yd, 3, seed=9, counter0=0)
+        assert np.array_equal(host(bd), b)  # the right-hand side is restored bit for bit
+        out.append(host(yd).copy())
+    assert np.abs(out[0] - out[1]).max() / np.abs(out[1]).max() < 1e-12
