@@ -146,6 +146,49 @@ def mgmc_lowrank_secondary(n: int = 257, levels: int = 5, k: int = 3, its: int =
     return {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample on A + B S B^T, k = {k} ball observations on every level (row-compact B, Bb), cholsampler of the explicit sum on {(n - 1) // 2 ** (levels - 1) + 1}^3", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "setup_s": setup_s, "finite": bool(torch.isfinite(y).all().item())}
 
 
+def unstructured_secondary(refine: int = 5, its: int = 50) -> dict:
+    """Secondary line (BASELINE config 4: "unstructured GAMG hierarchy on data/lshape.msh, AIJ SpMV path, multicolour
+    Gibbs, 1 GPU"): the reference's L-shape mesh (tests/golden/lshape.msh, a data fixture) refined `refine` times,
+    P1 matrix kappa^2 M + K, aggregation hierarchy (parmgmc_amd/unstructured.py, host set-up), then on the device
+    (a) the stand-alone multicolour Gibbs sampler on the fine MATAIJ matrix (sliced-ELL kernel, greedy colouring) and
+    (b) the MGMC chain on the hierarchy.  Not the headline metric."""
+    import torch
+
+    from parmgmc_amd import MCSOR, MGMC
+    from parmgmc_amd.unstructured import assemble_p1, build_hierarchy, read_gmsh41_triangles, refine_uniform
+
+    t0 = time.perf_counter()
+    xy, tris = read_gmsh41_triangles(ROOT / "tests" / "golden" / "lshape.msh")
+    for _ in range(refine):
+        xy, tris = refine_uniform(xy, tris)
+    A = assemble_p1(xy, tris, 1.0)
+    ops, ps = build_hierarchy(A, coarse_max=2000)
+    host_s = time.perf_counter() - t0
+    n, nnz = A.shape[0], A.nnz
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+
+    def timed(fn, reps):
+        fn(3, 0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(reps, 3)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    mc = MCSOR(A.indptr, A.indices, A.data).setup()
+    ncol = mc.get_num_colors()
+    ms_sweep = timed(lambda its_, c0: mc.sample(b, y, its_, seed=0xCAFE, counter0=c0, scaled=True), its)
+    mg = MGMC.from_hierarchy(ops, ps)
+    mg.set_smoother(True, 1.0, 1, 1)
+    mg.setup()
+    y.zero_()
+    ms_mg = timed(lambda its_, c0: mg.sample(b, y, its_, seed=0xCAFE, counter0=c0), its)
+    return {"workload": f"lshape.msh refined {refine}x: P1 kappa^2 M + K, {n} rows, {nnz} nonzeros; aggregation hierarchy {[len(o[0]) - 1 for o in ops]}", "gibbs_sweep": {"value": 1e3 / ms_sweep, "unit": "samples/s", "ms_per_sample": ms_sweep, "colors": ncol, "model_GBps_at_12nnz_plus_40N": (12 * nnz + 40 * n) / ms_sweep / 1e6}, "mgmc": {"value": 1e3 / ms_mg, "unit": "samples/s", "ms_per_sample": ms_mg, "levels": len(ops)}, "host_setup_s": host_s, "finite": bool(torch.isfinite(y).all().item())}
+
+
 def mgmc_dist_secondary(rank: int, world: int, transport, share: bool, n: int = 513, levels: int = 6, its: int = 10) -> dict:
     """Secondary line (BASELINE config 3 flavour, "512^3 DMDA V-cycle on 8 MI355X", on the PETSc-coarsenable 513^3 with
     6 levels so that the exact coarse sampler works on 17^3): samples/s of the MGMC chain on `world` z-slabs -- the
@@ -322,10 +365,11 @@ def main() -> None:
         try:
             if world == 1:
                 out["secondary_mgmc"] = mgmc_secondary()
-                try:
-                    out["secondary_mgmc_lowrank"] = mgmc_lowrank_secondary()
-                except Exception as e:  # noqa: BLE001
-                    out["secondary_mgmc_lowrank"] = {"error": f"{type(e).__name__}: {e}"}
+                for key, fn in (("secondary_mgmc_lowrank", mgmc_lowrank_secondary), ("secondary_unstructured", unstructured_secondary)):
+                    try:
+                        out[key] = fn()
+                    except Exception as e:  # noqa: BLE001
+                        out[key] = {"error": f"{type(e).__name__}: {e}"}
             sec = mgmc_dist_secondary(rank, world, "ipc" if (share and world > 1) else None, share, args.mgmc_n, args.mgmc_levels)
             if rank == 0:
                 out["secondary_mgmc_dist"] = sec

@@ -181,17 +181,15 @@ pmg_status pmg_dist_get_unique_id(const char *rccl_path, void *id128);
    loopback != 0, which makes the single rank its own z-neighbour for the HALO ONLY (exercises ncclSend/ncclRecv on
    one GPU; the ghost planes are written but never read because both slab faces are physical boundaries). */
 pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void *id128, const char *rccl_path, int loopback, pmg_dist *d);
-/* Transport "ipc": peer-to-peer copies of the boundary planes straight into the neighbour's receive block
-   (hipIpc memory + interprocess events) instead of RCCL kernels -- lower latency for the ~1 MB planes of a
-   strong-scaled grid.  token16: 16 random bytes shared by all ranks of the job (names the shared-memory segment
-   that carries the host-side sequence numbers).  Bootstrap: every rank creates, exports its blob
-   (pmg_dist_ipc_blob_bytes bytes), the launcher all-gathers the blobs, every rank connects to its two
-   z-neighbours' blobs (NULL at the ends), barrier, rank 0 unlinks.  All ranks on one node. */
-pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, const void *token16, pmg_dist *d);
+/* Transport "ipc": the face kernel stores its boundary planes straight into the neighbour's receive block (hipIpc
+   memory mapped over xGMI) and raises a flag word there; the neighbour's face stream waits for the flag on the device
+   -- no RCCL kernels, no host rendezvous; lower latency for the ~1 MB planes of a strong-scaled grid.  Bootstrap:
+   every rank creates, exports its blob (pmg_dist_ipc_blob_bytes bytes), the launcher all-gathers the blobs, every
+   rank connects to its two z-neighbours' blobs (NULL at the ends), barrier.  All ranks on one node. */
+pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dist *d);
 pmg_status pmg_dist_ipc_blob_bytes(int32_t *bytes);
 pmg_status pmg_dist_ipc_export(pmg_dist d, void *blob);
 pmg_status pmg_dist_ipc_connect(pmg_dist d, const void *blob_lo, const void *blob_hi);
-pmg_status pmg_dist_ipc_unlink(pmg_dist d);
 /* single rank as its own z-neighbour for the halo only (one-GPU timing / smoke test of the schedule) */
 pmg_status pmg_dist_ipc_connect_loopback(pmg_dist d);
 /* `its` samples of the sorgibbs (scaled = 0) / mcgibbs (scaled = 1) chain on this rank's slab, cvec vectors,

@@ -115,11 +115,10 @@ _sig = {
     "pmg_grid_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_dist_get_unique_id": (_int, [C.c_char_p, _vp]),
     "pmg_dist_create": (_int, [_vp, _i32, _i32, _vp, C.c_char_p, _int, C.POINTER(_vp)]),
-    "pmg_dist_create_ipc": (_int, [_vp, _i32, _i32, _vp, C.POINTER(_vp)]),
+    "pmg_dist_create_ipc": (_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "pmg_dist_ipc_blob_bytes": (_int, [C.POINTER(_i32)]),
     "pmg_dist_ipc_export": (_int, [_vp, _vp]),
     "pmg_dist_ipc_connect": (_int, [_vp, _vp, _vp]),
-    "pmg_dist_ipc_unlink": (_int, [_vp]),
     "pmg_dist_ipc_connect_loopback": (_int, [_vp]),
     "pmg_dist_sample_cvec": (_int, [_vp, _vp, _vp, _i32, _int, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_dist_destroy": (_int, [C.POINTER(_vp)]),

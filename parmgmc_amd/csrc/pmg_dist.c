@@ -95,8 +95,6 @@ struct pmg_dist_s {
   uint64_t      round[2];              /* pushes of colour c issued so far */
   uint64_t      ground;                /* generic exchanges issued so far  */
   int64_t       plane, gcap;
-  hipEvent_t    evP[2];                /* local: the initial push of colour c has read my boundary planes */
-  hipEvent_t    evW[2];                /* local: the neighbours' current colour-c planes have landed in my block */
   hipEvent_t    evT[PMG_IPC_WINDOW];   /* ring: compute-stream progress (interior planes of a colour done); also the host run-ahead throttle */
   uint64_t      nthrottle;
   hipEvent_t    evF[2];                /* local: face planes of colour c done (face stream) */
@@ -173,9 +171,8 @@ pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void 
 
 /* ---- IPC transport --------------------------------------------------------------------------------------- */
 
-pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, const void *token16, pmg_dist *out)
+pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dist *out)
 {
-  (void)token16; /* job token of the first version of this transport (host-side sequence numbers); unused */
   PMG_CHECK(out && g, PMG_ERR_ARG_NULL, "null argument");
   *out = NULL;
   PMG_CHECK(nranks >= 1 && nranks <= PMG_IPC_MAXRANKS && rank >= 0 && rank < nranks, PMG_ERR_ARG_OUTOFRANGE, "rank %d of %d", rank, nranks);
@@ -199,7 +196,7 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, const v
   d->grecv = d->block ? d->recv + 4 * d->plane : NULL;
   if (!st && hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "stream creation failed");
   for (int c = 0; c < 2 && !st; ++c) {
-    if (hipEventCreateWithFlags(&d->evB[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evP[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->evW[c], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
+    if (hipEventCreateWithFlags(&d->evB[c], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   }
   if (!st && hipEventCreateWithFlags(&d->evS, hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   for (int q = 0; q < PMG_IPC_WINDOW && !st; ++q)
@@ -266,13 +263,6 @@ pmg_status pmg_dist_ipc_connect_loopback(pmg_dist d)
     d->peer_recv[side]  = d->recv;
     d->peer_grecv[side] = d->grecv;
   }
-  return PMG_SUCCESS;
-}
-
-/* kept for callers of the first version of this transport (it removed a POSIX shared-memory name); nothing to do */
-pmg_status pmg_dist_ipc_unlink(pmg_dist d)
-{
-  PMG_CHECK(d && d->transport == 1, PMG_ERR_ARG_WRONG, "not an IPC dist object");
   return PMG_SUCCESS;
 }
 
@@ -395,10 +385,6 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
     (void)hipDeviceSynchronize();
     for (int side = 0; side < 2 && !d->loopback; ++side)
       if (d->peer_block[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
-    for (int c = 0; c < 2; ++c) {
-      if (d->evP[c]) (void)hipEventDestroy(d->evP[c]);
-      if (d->evW[c]) (void)hipEventDestroy(d->evW[c]);
-    }
     for (int q = 0; q < PMG_IPC_WINDOW; ++q)
       if (d->evT[q]) (void)hipEventDestroy(d->evT[q]);
     for (int c = 0; c < 2; ++c)

@@ -166,14 +166,12 @@ class IpcSlabDriver(RcclSlabDriver):
         self._h = C.c_void_p()
         self._grid = grid
         if loopback:
-            check(lib.pmg_dist_create_ipc(grid._h, 0, 1, C.create_string_buffer(os.urandom(16), 16), C.byref(self._h)))
+            check(lib.pmg_dist_create_ipc(grid._h, 0, 1, C.byref(self._h)))
             check(lib.pmg_dist_ipc_connect_loopback(self._h))
             return
         import torch.distributed as dist
 
-        tok = [os.urandom(16)]
-        dist.broadcast_object_list(tok, src=0, group=group)
-        check(lib.pmg_dist_create_ipc(grid._h, rank, world, C.create_string_buffer(tok[0], 16), C.byref(self._h)))
+        check(lib.pmg_dist_create_ipc(grid._h, rank, world, C.byref(self._h)))
         nb = C.c_int32()
         check(lib.pmg_dist_ipc_blob_bytes(C.byref(nb)))
         blob = C.create_string_buffer(nb.value)
