@@ -190,7 +190,14 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
   d->plane            = L.sp;
   d->gcap             = 2 * d->plane > ((int64_t)1 << 19) ? 2 * d->plane : ((int64_t)1 << 19); /* two colour planes of the fine level, or 4 MB */
   const size_t bytes  = sizeof(double) * (size_t)(PMG_IPC_HDR + 4 * d->plane + 4 * d->gcap);
-  if (!st && hipMalloc((void **)&d->block, bytes) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipMalloc of the halo receive block failed");
+  /* fine-grained device memory: flag words and planes are written by a PEER device while this device's kernels poll
+     / read them, so the block must be coherent at system scope without relying on cache flushes at kernel boundaries
+     (what RCCL does for its peer-written buffers); plain hipMalloc memory if the allocation flag is not supported */
+  if (!st && hipExtMallocWithFlags((void **)&d->block, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    d->block = NULL;
+    if (hipMalloc((void **)&d->block, bytes) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipMalloc of the halo receive block failed");
+  }
   if (!st && hipMemset(d->block, 0, bytes) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
   d->recv  = d->block ? d->block + PMG_IPC_HDR : NULL;
   d->grecv = d->block ? d->recv + 4 * d->plane : NULL;
