@@ -354,3 +354,26 @@ def test_woodbury_with_mgmc_sampler():
     y = dev(np.zeros(nx * ny))
     its, reason = pc.apply_richardson(dev(f), y, 50)
     assert (its, reason) == (50, 4) and np.isfinite(host(y)).all()
+
+
+def test_plain_c_driver_on_the_c_abi():
+    """examples/pmg_bench.c: a gcc-only program on include/parmgmc_hip.h (no Python, no torch in the process) that
+    mirrors the reference's benchmark loop (examples/benchmark/main.cc:105-149,261-309) -- burn-in, timed sampling,
+    IACT of a quantity of interest through the sample callback."""
+    import re
+    import subprocess
+    from pathlib import Path
+
+    exe = Path(__file__).resolve().parent.parent / "examples" / "pmg_bench"
+    assert exe.exists(), "build it with __graft_entry__.build()"
+    for args, expect_view in ((["-dim", "3", "-n", "33", "-pc_type", "mcgibbs", "-pc_mcgibbs_omega", "1.2", "-pc_mcgibbs_symmetric", "-view_sampler"], "Number of colours: 2"), (["-dim", "2", "-n", "65", "-pc_type", "gamgmc", "-gamgmc_pc_mg_levels", "3"], None)):
+        r = subprocess.run([str(exe), *args, "-n_burnin", "50", "-n_samples", "2000", "-measure_sampling_time", "-measure_iact"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        ms = float(re.search(r"Time per sample \[ms\]: ([0-9.]+)", r.stdout).group(1))
+        tau = float(re.search(r"IACT: ([0-9.]+)", r.stdout).group(1))
+        mean = float(re.search(r"Mean of the quantity of interest: ([-0-9.e]+)", r.stdout).group(1))
+        assert 0 < ms < 50 and 0.5 < tau < 50
+        # b = 1, kappa = 10: A^-1 b is 1/kappa^2 = 0.01 in the interior (row sums of A are kappa^2)
+        assert abs(mean - 0.01) < 0.003, r.stdout
+        if expect_view:
+            assert expect_view in r.stdout
