@@ -377,3 +377,27 @@ def test_plain_c_driver_on_the_c_abi():
         assert abs(mean - 0.01) < 0.003, r.stdout
         if expect_view:
             assert expect_view in r.stdout
+
+
+def test_ex1_at_the_reference_budget():
+    """reference examples/ex1.c:20 with ITS OWN budget and tolerance: 9x9 DMDA, kappa = 10, b = 1, -pc_type mcgibbs,
+    burn-in 10^4 (ex1.c:119), 10^6 samples (ex1.c:126), relative error of the sample mean < 0.02 (ex1.c:133-135)."""
+    import torch
+
+    from parmgmc_amd import pc as P
+
+    P.options_set_value("-pc_type", "mcgibbs")
+    A = P.Mat.dmda(9, 9, 1, 10.0)
+    pc = P.PC()
+    pc.set_operators(A)
+    pc.set_from_options()
+    pc.setup()
+    b, x = dev(np.ones(81)), dev(np.zeros(81))
+    pc.ksp_solve(b, x, 10_000, guess_nonzero=True)
+    acc = torch.zeros_like(x)
+    pc.set_sample_callback(lambda it, y: acc.add_(y), x)
+    n = 1_000_000
+    pc.ksp_solve(b, x, n, guess_nonzero=True)
+    ex = np.linalg.solve(O.shifted_laplace(9, 9, 1, 10.0).dense(), np.ones(81))
+    err = np.linalg.norm(host(acc) / n - ex) / np.linalg.norm(ex)
+    assert err < 0.02, err
