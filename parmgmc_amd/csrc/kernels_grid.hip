@@ -48,7 +48,26 @@ __device__ __forceinline__ double uniform(double v)
 // `halo.glo` / `halo.ghi` (one plane each, this rank's receive block) instead of the vector's own ghost planes, and
 // the results of plane 0 / nz-1 are ALSO stored into `halo.plo` / `halo.phi`, which point into the z-neighbours'
 // receive blocks (peer memory over xGMI): the halo exchange costs no extra launch and no copy.
-template <bool NOISY, bool OMEGA1, bool HALO>
+// entry nyz+1 / nyz+2 of an 8-entry operator table: wave-uniform (one line per wave) -> SGPR pair; PACKED (lanes of a
+// wave may sit on different lines) -> per-lane select chain
+template <bool PACKED>
+__device__ __forceinline__ double table_at(const double (&a)[8], int idx)
+{
+  if (!PACKED) return uniform(a[idx]);
+  double v = a[1];
+  v        = idx == 2 ? a[2] : v;
+  v        = idx == 3 ? a[3] : v;
+  v        = idx == 4 ? a[4] : v;
+  v        = idx == 5 ? a[5] : v;
+  v        = idx == 6 ? a[6] : v;
+  return v;
+}
+
+// PACKED: the threads of a plane are numbered line after line with tplE = ceil(ceil(nx/2)/2) threads per line and
+// dealt to the wavefronts without gaps.  With one line per wavefront (the default) a line of a 2^k+1 grid -- the
+// multigrid sizes -- needs one wavefront more than its power-of-two neighbour and leaves it almost empty (257: 65
+// threads in 128 lanes); packed, every wavefront is full.  Same arithmetic per point, so the results do not change.
+template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED>
 __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
 {
   // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
@@ -60,11 +79,18 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
 
   // grid = (8*nbx, band, nz) in XCD-banded order [the linear block id is blockIdx.x mod 8, so blockIdx.x & 7
   // is the XCD], or (nbx, nby, nz) in plain order
-  const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
-  const int k  = kbegin + (int)blockIdx.z * kstride;
-  const int t = bx * 64 + threadIdx.x;
-  const int j = by * 4 + ty;
+  const int k = kbegin + (int)blockIdx.z * kstride;
+  int       t, j;
+  if (PACKED) { // nbx = tplE here
+    const int flat = ((int)blockIdx.x * 4 + ty) * 64 + (int)threadIdx.x;
+    j              = flat / nbx;
+    t              = flat - j * nbx;
+  } else {
+    const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
+    t            = bx * 64 + threadIdx.x;
+    j            = by * 4 + ty;
+  }
   if (j >= L.ny || 2 * t >= L.sx) return;
   const int kg = k + L.kz0;
   const int p  = (c + j + kg) & 1;
@@ -93,7 +119,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
   // diagonal-dependent constants: the point has nyz in-domain y/z neighbours (wave-uniform) plus 1 or 2 in x
   const int    nyz = (int)hasS + (int)hasN + (int)hasD + (int)hasU;
   const bool   two0 = hasW0 && hasE0, two1 = hasE1;
-  const double idA = uniform(op.idiag[nyz + 1]), idB = uniform(op.idiag[nyz + 2]);
+  const double idA = table_at<PACKED>(op.idiag, nyz + 1), idB = table_at<PACKED>(op.idiag, nyz + 2);
   const double idg0 = two0 ? idB : idA, idg1 = two1 ? idB : idA;
   const double hS = hasS ? h2 : 0.0, hN = hasN ? h2 : 0.0, hD = hasD ? h2 : 0.0, hU = hasU ? h2 : 0.0;
 
@@ -101,7 +127,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
   if (NOISY) {
     double z0, z1;
     pmg::normal_pair((uint32_t)t, (uint32_t)(j + (int64_t)L.ny * kg), (uint32_t)op.sweep, ((uint32_t)(op.sweep >> 32) & 0x7fffffffu) | ((uint32_t)c << 31), op.key0, op.key1, tab, z0, z1);
-    const double sqA = uniform(op.sqrtdiag[nyz + 1]), sqB = uniform(op.sqrtdiag[nyz + 2]);
+    const double sqA = table_at<PACKED>(op.sqrtdiag, nyz + 1), sqB = table_at<PACKED>(op.sqrtdiag, nyz + 2);
     const double sq0 = two0 ? sqB : sqA, sq1 = two1 ? sqB : sqA;
     w0 = z0 * sq0 + bb.x;
     w1 = z1 * sq1 + bb.y;
@@ -165,14 +191,22 @@ __global__ void grid_from_cvec_kernel(pmgk_grid_layout L, const double *__restri
 // r = b - A y on cvecs, one colour per launch, same tiling and XCD-banded order as the sweep.  Row sum in CSR
 // storage order INCLUDING the diagonal at its place (what PETSc MatMult does), then r = b - s
 // (VecAYPX(w,-1,b), reference src/pc_gamgmc.c:253-254).
-__global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int bandw, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+template <bool PACKED>
+__global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int bandw, int tplE, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
 {
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
   const int k  = blockIdx.z;
-  const int t  = bx * 64 + threadIdx.x;
-  const int j  = by * 4 + ty;
+  int       t, j;
+  if (PACKED) {
+    const int flat = ((int)blockIdx.x * 4 + ty) * 64 + (int)threadIdx.x;
+    j              = flat / tplE;
+    t              = flat - j * tplE;
+  } else {
+    const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
+    t            = bx * 64 + threadIdx.x;
+    j            = by * 4 + ty;
+  }
   if (j >= L.ny || 2 * t >= L.sx) return;
   const int kg = k + L.kz0;
   const int p  = (c + j + kg) & 1;
@@ -194,7 +228,7 @@ __global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, 
   const double  L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
   const bool    hasW0 = i0 > 0, hasE0 = i0 < L.nx - 1, hasE1 = i1 < L.nx - 1;
   const int     nyz = (int)hasS + (int)hasN + (int)hasD + (int)hasU;
-  const double  dA = uniform(op.diag[nyz + 1]), dB = uniform(op.diag[nyz + 2]);
+  const double  dA = table_at<PACKED>(op.diag, nyz + 1), dB = table_at<PACKED>(op.diag, nyz + 2);
   const double  dg0 = (hasW0 && hasE0) ? dB : dA, dg1 = hasE1 ? dB : dA;
   const double  a = -op.h2;
   const double  aS = hasS ? a : 0.0, aN = hasN ? a : 0.0, aD = hasD ? a : 0.0, aU = hasU ? a : 0.0;
@@ -221,51 +255,80 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
 
+// threads per line that own a point, and whether packing the lines into wavefronts pays: one line per wavefront
+// fills at most two thirds of its lanes (257^3: 165 -> 129 us per sweep; at 513^3, 67 % full, the XCD-banded order of
+// the unpacked mapping is worth more: 857 vs 883 us)
+static inline int grid_threads_per_line(const pmgk_grid_layout *L) { return ((L->nx + 1) / 2 + 1) / 2; }
+static inline bool grid_use_packed(const pmgk_grid_layout *L)
+{
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("PMG_GRID_PACKED");
+    env           = e ? atoi(e) : 2; // 0 = never, 1 = always, 2 = by lane efficiency
+  }
+  if (env != 2) return env == 1;
+  const int tplE = grid_threads_per_line(L), lanes = (L->sx / 2 + 63) / 64 * 64;
+  return 2 * lanes >= 3 * tplE;
+}
+
+template <bool NOISY, bool OMEGA1, bool HALO>
+static void launch_sweep(bool packed, dim3 grid, dim3 block, hipStream_t s, const pmgk_grid_layout &L, const pmgk_grid_op &op, int color, int nbx, int nby, int bandw, int kbegin, int kstride, const pmgk_grid_halo &h, const double *bo, const double *yo, double *ys)
+{
+  if (packed) hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, true>), grid, block, 0, s, L, op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+  else hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, false>), grid, block, 0, s, L, op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+}
+
 extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, int kstride, const pmgk_grid_halo *halo, const double *b, double *y, void *stream)
 {
   if (kcount <= 0) return 0;
-  const int tpl = L->sx / 2; // threads per line
-  const int nbx = (tpl + 63) / 64, nby = (L->ny + 3) / 4;
+  const int  tpl    = L->sx / 2; // threads per line
+  const bool packed = grid_use_packed(L);
+  const int  tplE   = grid_threads_per_line(L);
+  const int  nbx = packed ? tplE : (tpl + 63) / 64, nby = (L->ny + 3) / 4;
   static int banded_env = -1;
   if (banded_env < 0) {
     const char *e = getenv("PMG_GRID_BANDED");
     banded_env    = e ? atoi(e) : 1;
   }
   // XCD-banded dispatch order needs enough line tiles to give every XCD a band
-  const int  bandw = (banded_env && nby >= 16) ? (nby + 7) / 8 : 0;
+  const int  bandw = (!packed && banded_env && nby >= 16) ? (nby + 7) / 8 : 0;
   const dim3 block(64, 4, 1);
-  const dim3 grid(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, kcount);
+  const dim3 grid = packed ? dim3((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, kcount) : dim3(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, kcount);
   hipStream_t   s  = (hipStream_t)stream;
   const double *bo = b + (int64_t)color * L->cs, *yo = y + (int64_t)(1 - color) * L->cs;
   double       *ys = y + (int64_t)color * L->cs;
-  pmgk_grid_halo h0 = {nullptr, nullptr, nullptr, nullptr};
+  const pmgk_grid_halo h0 = {nullptr, nullptr, nullptr, nullptr};
   if (halo) {
-    const pmgk_grid_halo h = *halo;
     if (op->noisy) {
-      if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
-      else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+      if (op->omega_is_one) launch_sweep<true, true, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);
+      else launch_sweep<true, false, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);
     } else {
-      if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
-      else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false, true>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+      if (op->omega_is_one) launch_sweep<false, true, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);
+      else launch_sweep<false, false, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);
     }
   } else if (op->noisy) {
-    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<true, true, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
-    else hipLaunchKernelGGL((grid_color_sweep_kernel<true, false, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
+    if (op->omega_is_one) launch_sweep<true, true, false>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
+    else launch_sweep<true, false, false>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
   } else {
-    if (op->omega_is_one) hipLaunchKernelGGL((grid_color_sweep_kernel<false, true, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
-    else hipLaunchKernelGGL((grid_color_sweep_kernel<false, false, false>), grid, block, 0, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
+    if (op->omega_is_one) launch_sweep<false, true, false>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
+    else launch_sweep<false, false, false>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
   }
   return launch_status();
 }
 
 extern "C" int pmgk_grid_residual(const pmgk_grid_layout *L, const pmgk_grid_op *op, const double *b, const double *y, double *r, void *stream)
 {
-  const int  tpl = L->sx / 2;
+  const int  tpl    = L->sx / 2;
+  const bool packed = grid_use_packed(L);
+  const int  tplE   = grid_threads_per_line(L);
   const int  nbx = (tpl + 63) / 64, nby = (L->ny + 3) / 4;
-  const int  bandw = nby >= 16 ? (nby + 7) / 8 : 0;
+  const int  bandw = (!packed && nby >= 16) ? (nby + 7) / 8 : 0;
   const dim3 block(64, 4, 1);
-  const dim3 grid(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, L->nz);
-  for (int c = 0; c < 2; ++c) hipLaunchKernelGGL(grid_residual_kernel, grid, block, 0, (hipStream_t)stream, *L, *op, c, bandw, b, y, r);
+  const dim3 grid = packed ? dim3((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, L->nz) : dim3(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, L->nz);
+  for (int c = 0; c < 2; ++c) {
+    if (packed) hipLaunchKernelGGL(grid_residual_kernel<true>, grid, block, 0, (hipStream_t)stream, *L, *op, c, bandw, tplE, b, y, r);
+    else hipLaunchKernelGGL(grid_residual_kernel<false>, grid, block, 0, (hipStream_t)stream, *L, *op, c, bandw, tplE, b, y, r);
+  }
   return launch_status();
 }
 
