@@ -36,9 +36,13 @@ __global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int 
   }
   if (NOISY) pmg::load_log_table(s_logtab);
   __syncthreads();
-  const int ii = blockIdx.x * 256 + tid; // index within the colour along x
-  const int i = 2 * ii + px, j = 2 * (int)blockIdx.y + py, k = 2 * (int)blockIdx.z + kfirst; // k: global plane
-  if (i >= S.nx || j >= S.ny || k >= S.kz0 + S.nz) return;
+  // the points of this colour in one plane, numbered line after line and dealt to the threads without gaps (a line
+  // of a 2^k+1 grid has 2^(k-1)+1 points of a colour: one line per block would leave most lanes idle)
+  const int cx   = (S.nx - px + 1) / 2;
+  const int flat = blockIdx.x * 256 + tid;
+  const int jj   = flat / cx, ii = flat - jj * cx;
+  const int i = 2 * ii + px, j = 2 * jj + py, k = 2 * (int)blockIdx.z + kfirst; // k: global plane
+  if (j >= S.ny || k >= S.kz0 + S.nz) return;
   const int64_t row  = i + (int64_t)S.nx * (j + (int64_t)S.ny * k); // global natural index: the noise counter
   const int64_t lrow = i + (int64_t)S.nx * (j + (int64_t)S.ny * (k - S.kz0 + 1));
   const int     cls  = pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nzg);
@@ -73,8 +77,8 @@ __global__ __launch_bounds__(256) void st27_residual_kernel(pmgk_st27 S, const d
   __shared__ double s_coef[27 * 27];
   for (int q = threadIdx.x; q < 27 * 27; q += 256) s_coef[q] = S.coef[q];
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = S.kz0 + blockIdx.z; // k: global plane
-  if (i >= S.nx) return;
+  const int flat = blockIdx.x * 256 + threadIdx.x, j = flat / S.nx, i = flat - j * S.nx, k = S.kz0 + blockIdx.z; // k: global plane
+  if (j >= S.ny) return;
   const int64_t row = i + (int64_t)S.nx * (j + (int64_t)S.ny * (k - S.kz0 + 1));
   const double *cf  = s_coef + 27 * (pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nzg));
   double        sum = 0.0;
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(256) void st27_residual_kernel(pmgk_st27 S, const d
 // 2K, its restriction reads the fine planes 2K-1 .. 2K+1 (the outer ones may be ghost planes of r).
 __global__ __launch_bounds__(256) void st27_restrict_kernel(pmgk_st27_dims F, pmgk_st27_dims C, const double *__restrict__ r, double *__restrict__ bc)
 {
-  const int I = blockIdx.x * 256 + threadIdx.x, J = blockIdx.y, K = C.kz0 + blockIdx.z;
-  if (I >= C.nx) return;
+  const int flat = blockIdx.x * 256 + threadIdx.x, J = flat / C.nx, I = flat - J * C.nx, K = C.kz0 + blockIdx.z;
+  if (J >= C.ny) return;
   const int rx = F.nx != C.nx, ry = F.ny != C.ny, rz = F.nzg != C.nzg;
   const int fi = rx ? 2 * I : I, fj = ry ? 2 * J : J, fk = rz ? 2 * K : K;
   double    s  = 0.0;
@@ -121,8 +125,8 @@ __global__ __launch_bounds__(256) void st27_restrict_kernel(pmgk_st27_dims F, pm
 // interpolated values every device can form from its own coarse planes + coarse ghost planes
 __global__ __launch_bounds__(256) void st27_prolong_add_kernel(pmgk_st27_dims F, pmgk_st27_dims C, int kbegin, const double *__restrict__ ec, double *__restrict__ x)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = kbegin + blockIdx.z;
-  if (i >= F.nx) return;
+  const int flat = blockIdx.x * 256 + threadIdx.x, j = flat / F.nx, i = flat - j * F.nx, k = kbegin + blockIdx.z;
+  if (j >= F.ny) return;
   const int    rx = F.nx != C.nx, ry = F.ny != C.ny, rz = F.nzg != C.nzg;
   const int    I0 = rx ? i >> 1 : i, J0 = ry ? j >> 1 : j, K0 = rz ? k >> 1 : k;
   const int    mx = (rx && (i & 1)) ? 2 : 1, my = (ry && (j & 1)) ? 2 : 1, mz = (rz && (k & 1)) ? 2 : 1;
@@ -151,7 +155,7 @@ extern "C" int pmgk_st27_sweep_phase(const pmgk_st27 *S, int backward, int phase
     const int kfirst = S->kz0 + ((pz - S->kz0) & 1); // first owned plane of parity pz
     const int cx = (S->nx - px + 1) / 2, cy = (S->ny - py + 1) / 2, cz = (S->kz0 + S->nz - kfirst + 1) / 2; // points of this parity
     if (cx <= 0 || cy <= 0 || cz <= 0) continue;
-    const dim3 grid((cx + 255) / 256, cy, cz), block(256);
+    const dim3 grid((unsigned)(((int64_t)cx * cy + 255) / 256), 1, cz), block(256);
     if (noisy) hipLaunchKernelGGL((st27_color_sweep_kernel<true>), grid, block, 0, (hipStream_t)stream, *S, px, py, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
     else hipLaunchKernelGGL((st27_color_sweep_kernel<false>), grid, block, 0, (hipStream_t)stream, *S, px, py, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
   }
@@ -168,20 +172,20 @@ extern "C" int pmgk_st27_sweep(const pmgk_st27 *S, int backward, double omega, i
 extern "C" int pmgk_st27_residual(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream)
 {
   if (S->nz <= 0) return 0;
-  hipLaunchKernelGGL(st27_residual_kernel, dim3((S->nx + 255) / 256, S->ny, S->nz), dim3(256), 0, (hipStream_t)stream, *S, b, y, r);
+  hipLaunchKernelGGL(st27_residual_kernel, dim3((unsigned)(((int64_t)S->nx * S->ny + 255) / 256), 1, S->nz), dim3(256), 0, (hipStream_t)stream, *S, b, y, r);
   return launch_status();
 }
 
 extern "C" int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims *C, const double *r, double *bc, void *stream)
 {
   if (C->nz <= 0) return 0;
-  hipLaunchKernelGGL(st27_restrict_kernel, dim3((C->nx + 255) / 256, C->ny, C->nz), dim3(256), 0, (hipStream_t)stream, *F, *C, r, bc);
+  hipLaunchKernelGGL(st27_restrict_kernel, dim3((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, C->nz), dim3(256), 0, (hipStream_t)stream, *F, *C, r, bc);
   return launch_status();
 }
 
 extern "C" int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_dims *C, int kbegin, int kcount, const double *ec, double *x, void *stream)
 {
   if (kcount <= 0) return 0;
-  hipLaunchKernelGGL(st27_prolong_add_kernel, dim3((F->nx + 255) / 256, F->ny, kcount), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, ec, x);
+  hipLaunchKernelGGL(st27_prolong_add_kernel, dim3((unsigned)(((int64_t)F->nx * F->ny + 255) / 256), 1, kcount), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, ec, x);
   return launch_status();
 }

@@ -27,8 +27,8 @@ __device__ __forceinline__ int64_t coarse_pos(const pmgk_st27_dims &C, const int
 // b_c(I) = sum over the <= 27 fine points 2I+d, d in {-1,0,1}^3 (only refined directions), of w(d) r(2I+d); K global
 __global__ __launch_bounds__(256) void q1_restrict_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int rx, int ry, int rz, const int32_t *__restrict__ cpos, const double *__restrict__ r, double *__restrict__ bc)
 {
-  const int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y, K = C.kz0 + blockIdx.z;
-  if (I >= C.nx) return;
+  const int flat = blockIdx.x * blockDim.x + threadIdx.x, J = flat / C.nx, I = flat - J * C.nx, K = C.kz0 + blockIdx.z; // lines packed into the wavefronts
+  if (J >= C.ny) return;
   const int fi = rx ? 2 * I : I, fj = ry ? 2 * J : J, fk = rz ? 2 * K : K;
   double    s  = 0.0;
   for (int dz = rz ? -1 : 0; dz <= (rz ? 1 : 0); ++dz) {
@@ -65,9 +65,11 @@ __device__ __forceinline__ double q1_interp_point(int i, int j, int k, const pmg
 
 typedef double d2t __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void q1_prolong_add_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int rx, int ry, int rz, int kbegin, const int32_t *__restrict__ cpos, const double *__restrict__ ec, double *__restrict__ x)
+__global__ __launch_bounds__(256) void q1_prolong_add_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int rx, int ry, int rz, int kbegin, int tplE, const int32_t *__restrict__ cpos, const double *__restrict__ ec, double *__restrict__ x)
 {
-  const int t = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = kbegin + (int)(blockIdx.z >> 1), c = blockIdx.z & 1; // k: local plane, -1 / nz = ghosts
+  // tplE threads per line own a point; the lines of a plane are packed into the wavefronts without gaps
+  const int flat = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x, j = flat / tplE, t = flat - j * tplE;
+  const int k = kbegin + (int)(blockIdx.z >> 1), c = blockIdx.z & 1; // k: local plane, -1 / nz = ghosts
   if (j >= L.ny || 2 * t >= L.sx) return;
   const int p  = (c + j + k + L.kz0) & 1;
   const int i0 = 4 * t + p, i1 = i0 + 2;
@@ -87,7 +89,7 @@ extern "C" int pmgk_q1_restrict(const pmgk_grid_layout *L, const pmgk_st27_dims 
 {
   if (C->nz <= 0) return 0;
   const int  rx = C->nx != L->nx, ry = C->ny != L->ny, rz = C->nzg != L->nzg;
-  const dim3 block(64), grid((C->nx + 63) / 64, C->ny, C->nz);
+  const dim3 block(256), grid((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, C->nz);
   hipLaunchKernelGGL(q1_restrict_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, cpos, r_cvec, bc);
   return launch_status();
 }
@@ -96,7 +98,8 @@ extern "C" int pmgk_q1_prolong_add(const pmgk_grid_layout *L, const pmgk_st27_di
 {
   if (kcount <= 0) return 0;
   const int  rx = C->nx != L->nx, ry = C->ny != L->ny, rz = C->nzg != L->nzg;
-  const dim3 block(64, 4), grid((L->sx / 2 + 63) / 64, (L->ny + 3) / 4, 2 * kcount);
-  hipLaunchKernelGGL(q1_prolong_add_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, kbegin, cpos, ec, x_cvec);
+  const int  tplE = ((L->nx + 1) / 2 + 1) / 2;
+  const dim3 block(64, 4), grid((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, 2 * kcount);
+  hipLaunchKernelGGL(q1_prolong_add_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, kbegin, tplE, cpos, ec, x_cvec);
   return launch_status();
 }
