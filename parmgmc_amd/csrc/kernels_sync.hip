@@ -36,9 +36,81 @@ __global__ void flag_wait_kernel(const uint64_t *f0, const uint64_t *f1, uint64_
   }
 }
 
+// ---- generic neighbour exchange in two launches -----------------------------------------------------------------
+// push : copy up to PMGK_XCH_MAXSEG segments into the neighbours' message slots (peer stores), then the LAST block to
+//        finish raises the neighbours' flag words (every thread fences its stores at system scope first);
+// pull : every block waits for my flag words, then the segments are copied out of my slots.  The slots live in
+//        fine-grained memory, so the loads after the acquire see the peer's stores without a kernel boundary.
+__device__ __forceinline__ void copy_segments(const pmgk_xch_args &a)
+{
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  for (int q = 0; q < a.nseg; ++q) {
+    const double *__restrict__ src = a.src[q];
+    double *__restrict__ dst       = a.dst[q];
+    for (int64_t i = tid; i < a.n[q]; i += nth) dst[i] = src[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void xch_push_kernel(pmgk_xch_args a, unsigned *counter)
+{
+  copy_segments(a);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = atomicAdd(counter, 1u);
+    if (done == gridDim.x - 1) {
+      *counter = 0;
+      __threadfence_system();
+      if (a.flag[0]) __hip_atomic_store(a.flag[0], a.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.flag[1]) __hip_atomic_store(a.flag[1], a.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void xch_pull_kernel(pmgk_xch_args a, unsigned *err)
+{
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    ok = 1;
+    for (int q = 0; q < 2 && ok; ++q) {
+      if (!a.flag[q]) continue;
+      unsigned long long spins = 0;
+      while (__hip_atomic_load(a.flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.value) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1ull << 24)) {
+          if (err) atomicExch(err, 1u);
+          ok = 0;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  copy_segments(a);
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
+
+extern "C" int pmgk_xch_push(const pmgk_xch_args *a, unsigned *counter, void *stream)
+{
+  int64_t total = 0;
+  for (int q = 0; q < a->nseg; ++q) total += a->n[q];
+  const int nb = total > 0 ? (int)((total + 4095) / 4096 < 64 ? (total + 4095) / 4096 : 64) : 1;
+  hipLaunchKernelGGL(xch_push_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, counter);
+  return launch_status();
+}
+
+extern "C" int pmgk_xch_pull(const pmgk_xch_args *a, unsigned *err, void *stream)
+{
+  int64_t total = 0;
+  for (int q = 0; q < a->nseg; ++q) total += a->n[q];
+  const int nb = total > 0 ? (int)((total + 4095) / 4096 < 64 ? (total + 4095) / 4096 : 64) : 1;
+  hipLaunchKernelGGL(xch_pull_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, err);
+  return launch_status();
+}
 
 extern "C" int pmgk_flag_signal(uint64_t *p0, uint64_t v0, uint64_t *p1, uint64_t v1, void *stream)
 {

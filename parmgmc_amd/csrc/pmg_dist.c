@@ -99,6 +99,7 @@ struct pmg_dist_s {
   uint64_t      nthrottle;
   hipEvent_t    evF[2];                /* local: face planes of colour c done (face stream) */
   unsigned     *err_dev;               /* pinned host word (device-visible), set by a flag wait that gave up */
+  unsigned     *xch_counter;           /* device: blocks of the push kernel that have finished */
   pmg_grid      g;
   int           rank, nranks, lo, hi; /* z-neighbours (-1 = physical boundary); lo == hi == rank in loopback mode */
   int           loopback;
@@ -212,6 +213,8 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
     if (hipEventCreateWithFlags(&d->evF[c], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   if (!st && hipHostMalloc((void **)&d->err_dev, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipHostMalloc failed");
   if (!st) *d->err_dev = 0;
+  if (!st) st = pmg_dev_alloc((void **)&d->xch_counter, sizeof(unsigned));
+  if (!st && hipMemset(d->xch_counter, 0, sizeof(unsigned)) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
   if (st) {
     pmg_dist_destroy(&d);
     return st;
@@ -397,6 +400,7 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
     for (int c = 0; c < 2; ++c)
       if (d->evF[c]) (void)hipEventDestroy(d->evF[c]);
     if (d->err_dev) (void)hipHostFree(d->err_dev);
+    pmg_dev_free(d->xch_counter);
     if (d->block) (void)hipFree(d->block);
   }
   if (d->comm && d->api.CommDestroy) d->api.CommDestroy(d->comm);
@@ -449,30 +453,38 @@ pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo,
     PMG_HIP(hipStreamWaitEvent(s, d->evGx, 0));
     return PMG_SUCCESS;
   }
-  /* IPC: everything on the caller's stream -- push my segments into the neighbours' slots of parity p, raise their
-     flags, wait for mine, copy out */
+  /* IPC: two launches on the caller's stream -- push my segments into the neighbours' slots of parity p and raise
+     their flags; wait for mine and copy the messages out */
   PMG_CALL(ipc_check(d));
   const int p = (int)(d->ground & 1);
   d->ground += 1;
+  pmgk_xch_args push, pull;
+  memset(&push, 0, sizeof push);
+  memset(&pull, 0, sizeof pull);
+  push.value = pull.value = d->ground;
   for (int side = 0; side < 2; ++side) {
     if (nb[side] < 0) continue;
-    int64_t off = 0;
+    int64_t off = 0, roff = 0;
     for (int q = 0; q < nseg; ++q) {
-      PMG_CHECK(off + ns[side][q] <= d->gcap, PMG_ERR_ARG_SIZ, "exchange of %lld doubles exceeds the receive block (%lld)", (long long)(off + ns[side][q]), (long long)d->gcap);
-      if (ns[side][q] > 0) PMG_HIP(hipMemcpyAsync(d->peer_grecv[side] + (int64_t)(p * 2 + (1 - side)) * d->gcap + off, snd[side][q], sizeof(double) * (size_t)ns[side][q], hipMemcpyDeviceToDevice, s));
+      PMG_CHECK(off + ns[side][q] <= d->gcap && roff + nr[side][q] <= d->gcap, PMG_ERR_ARG_SIZ, "exchange of %lld doubles exceeds the receive block (%lld)", (long long)(off + ns[side][q]), (long long)d->gcap);
+      if (ns[side][q] > 0) {
+        push.src[push.nseg] = snd[side][q];
+        push.dst[push.nseg] = d->peer_grecv[side] + (int64_t)(p * 2 + (1 - side)) * d->gcap + off;
+        push.n[push.nseg++] = ns[side][q];
+      }
+      if (nr[side][q] > 0) {
+        pull.src[pull.nseg] = d->grecv + (int64_t)(p * 2 + side) * d->gcap + roff;
+        pull.dst[pull.nseg] = rcv[side][q];
+        pull.n[pull.nseg++] = nr[side][q];
+      }
       off += ns[side][q];
+      roff += nr[side][q];
     }
+    push.flag[side] = flag_peer(d, side, 4 + (1 - side));
+    pull.flag[side] = flag_mine(d, 4 + side);
   }
-  PMG_KERNEL(pmgk_flag_signal(flag_peer(d, 0, 4 + 1), d->ground, flag_peer(d, 1, 4 + 0), d->ground, s));
-  PMG_KERNEL(pmgk_flag_wait(nb[0] >= 0 ? flag_mine(d, 4 + 0) : NULL, d->ground, nb[1] >= 0 ? flag_mine(d, 4 + 1) : NULL, d->ground, d->err_dev, s));
-  for (int side = 0; side < 2; ++side) {
-    if (nb[side] < 0) continue;
-    int64_t off = 0;
-    for (int q = 0; q < nseg; ++q) {
-      if (nr[side][q] > 0) PMG_HIP(hipMemcpyAsync(rcv[side][q], d->grecv + (int64_t)(p * 2 + side) * d->gcap + off, sizeof(double) * (size_t)nr[side][q], hipMemcpyDeviceToDevice, s));
-      off += nr[side][q];
-    }
-  }
+  PMG_KERNEL(pmgk_xch_push(&push, d->xch_counter, s));
+  PMG_KERNEL(pmgk_xch_pull(&pull, d->err_dev, s));
   return ipc_throttle(d, s);
 }
 
