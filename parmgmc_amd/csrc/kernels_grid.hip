@@ -13,6 +13,7 @@
 // a = -h2 the reference's "sum -= a*y" equals "sum += h2*y" bit for bit.  The file is compiled with
 // -ffp-contract=off (no FMA contraction), like the CPU oracle.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdlib.h>
 #include "pmg_kernels.h"
 #include "pmg_rng.hpp"
@@ -67,19 +68,27 @@ __device__ __forceinline__ double table_at(const double (&a)[8], int idx)
 // dealt to the wavefronts without gaps.  With one line per wavefront (the default) a line of a 2^k+1 grid -- the
 // multigrid sizes -- needs one wavefront more than its power-of-two neighbour and leaves it almost empty (257: 65
 // threads in 128 lanes); packed, every wavefront is full.  Same arithmetic per point, so the results do not change.
-template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED>
-__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+// one wavefront waits (lane 0 polls, the others follow) until *f >= v; gives up after ~10 s.  The flag words and the
+// planes they announce live in FINE-GRAINED memory (never cached in L2), so relaxed polls and a plain ordering fence
+// are enough -- a system-scope acquire would invalidate the L2 under the interior sweep on every poll.
+__device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, unsigned *err)
 {
-  // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
-  // wave-uniform; readfirstlane tells the compiler, which then keeps the boundary logic on the scalar unit
-  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  __shared__ pmg::LogTabEntry s_logtab[NOISY ? 4 * PMG_LOGTAB_SIZE : 1];
-  const pmg::LogTabEntry     *tab = s_logtab + (NOISY ? ty * PMG_LOGTAB_SIZE : 0);
-  if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x);
+  if (threadIdx.x == 0) {
+    unsigned long long spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1ull << 26)) {
+        if (err) atomicExch(err, 1u);
+        break;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
-  // grid = (8*nbx, band, nz) in XCD-banded order [the linear block id is blockIdx.x mod 8, so blockIdx.x & 7
-  // is the XCD], or (nbx, nby, nz) in plain order
-  const int k = kbegin + (int)blockIdx.z * kstride;
+template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED>
+__device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L, const pmgk_grid_op &op, int c, int nbx, int nby, int bandw, int k, int ty, const pmg::LogTabEntry *tab, const pmgk_grid_halo &halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+{
   int       t, j;
   if (PACKED) { // nbx = tplE here
     const int flat = ((int)blockIdx.x * 4 + ty) * 64 + (int)threadIdx.x;
@@ -165,6 +174,49 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
     if (k == 0 && halo.plo) *reinterpret_cast<d2 *>(halo.plo + inplane) = out;
     if (k == L.nz - 1 && halo.phi) *reinterpret_cast<d2 *>(halo.phi + inplane) = out;
   }
+}
+
+template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED>
+__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+{
+  // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
+  // wave-uniform; readfirstlane tells the compiler, which then keeps the boundary logic on the scalar unit
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  __shared__ pmg::LogTabEntry s_logtab[NOISY ? 4 * PMG_LOGTAB_SIZE : 1];
+  const pmg::LogTabEntry     *tab = s_logtab + (NOISY ? ty * PMG_LOGTAB_SIZE : 0);
+  if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x);
+
+  // grid = (8*nbx, band, nz) in XCD-banded order [the linear block id is blockIdx.x mod 8, so blockIdx.x & 7
+  // is the XCD], or (nbx, nby, nz) in plain order
+  int k = kbegin + (int)blockIdx.z * kstride;
+  if (HALO && halo.full) { // face planes first: they carry the halo traffic
+    const int z = (int)blockIdx.z;
+    k           = z == 0 ? 0 : (z == 1 ? L.nz - 1 : z - 1);
+    const bool face_lo = k == 0, face_hi = k == L.nz - 1;
+    if (face_lo && halo.wlo) wave_wait_flag(halo.wlo, halo.wval, halo.err);
+    if (face_hi && halo.whi) wave_wait_flag(halo.whi, halo.wval, halo.err);
+    grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, nbx, nby, bandw, k, ty, tab, halo, b_own, y_other, y_own);
+    if (face_lo || face_hi) { // every block of a face plane reports; the last one tells the neighbours
+      // the peer stores went to fine-grained memory (write-through, not held in L2): waiting for their completion is
+      // all a wavefront has to do -- a system-scope release here would write the L2 back once per wavefront while
+      // the interior blocks are filling it (measured: 2.5x slower)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads(); // one report per block: thousands of wavefronts on one counter would queue up at the L2
+      if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned nface  = L.nz > 1 ? 2u : 1u;
+        const unsigned expect = gridDim.x * gridDim.y * nface;
+        if (atomicAdd(halo.counter, 1u) == expect - 1u) {
+          *halo.counter = 0;
+          // every face wavefront waited for the completion of its peer stores before it reported, so the planes are
+          // in the neighbours' memory: a relaxed store of the flag word is ordered behind them
+          if (halo.slo) __hip_atomic_store(halo.slo, halo.sval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (halo.shi) __hip_atomic_store(halo.shi, halo.sval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    return;
+  }
+  grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, nbx, nby, bandw, k, ty, tab, halo, b_own, y_other, y_own);
 }
 
 // natural (DMDA, i fastest) <-> colour-partitioned storage
@@ -297,7 +349,8 @@ extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_
   hipStream_t   s  = (hipStream_t)stream;
   const double *bo = b + (int64_t)color * L->cs, *yo = y + (int64_t)(1 - color) * L->cs;
   double       *ys = y + (int64_t)color * L->cs;
-  const pmgk_grid_halo h0 = {nullptr, nullptr, nullptr, nullptr};
+  pmgk_grid_halo h0;
+  memset(&h0, 0, sizeof h0);
   if (halo) {
     if (op->noisy) {
       if (op->omega_is_one) launch_sweep<true, true, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);

@@ -13,14 +13,15 @@
  * is what makes re-use of the send and ghost planes safe without further flags.  Noise depends on global indices
  * only: the chain is bit-identical for every number of devices.
  *
- * Second transport, "ipc" (same schedule, for the latency-bound strong-scaling regime where a 1 MB RCCL send/recv
- * kernel costs ~40 us): every rank owns one receive block (flag words, one plane per colour and side, a generic
- * message area) exported with hipIpcGetMemHandle.  A push writes the boundary plane INTO the neighbour's block over
- * xGMI (the face kernel stores there directly) and then raises a flag word in the same block to the round number
- * with hipStreamWriteValue64; the receiver's stream waits for the flag with hipStreamWaitValue64 and reads the
- * plane.  Everything is stream-ordered on the devices: no host rendezvous, no interprocess events (the runtime
- * caps those at 32 records and services every wait on one from a host thread), ~9 us per flag round trip measured
- * between two processes.  The host only throttles itself to a few rounds ahead of its device.
+ * Second transport, "ipc" (for the latency-bound strong-scaling regime where a 1 MB RCCL send/recv kernel costs
+ * ~40 us): every rank owns one receive block in fine-grained device memory (flag words, one plane per colour and
+ * side, a generic message area) exported with hipIpcGetMemHandle.  The sweep kernel of a colour takes the two face
+ * planes first: their wavefronts wait, inside the kernel, for the flag words that announce the neighbours' planes of
+ * the other colour, read those planes from the block, store the new planes into y AND into the neighbours' blocks over
+ * xGMI, and the last face wavefront raises the neighbours' flag words; the other blocks of the same launch sweep the
+ * interior.  One launch per colour, one stream, no events, no host rendezvous (interprocess events are capped at 32
+ * records by the runtime and serviced by a host thread); the host only throttles itself to a few rounds ahead of its
+ * device.
  *
  * RCCL is loaded at run time (dlopen of the path the caller names -- the copy PyTorch bundles when used beside
  * torch, so that the process keeps one RCCL and one HIP runtime); no link-time dependency.
@@ -95,9 +96,8 @@ struct pmg_dist_s {
   uint64_t      round[2];              /* pushes of colour c issued so far */
   uint64_t      ground;                /* generic exchanges issued so far  */
   int64_t       plane, gcap;
-  hipEvent_t    evT[PMG_IPC_WINDOW];   /* ring: compute-stream progress (interior planes of a colour done); also the host run-ahead throttle */
+  hipEvent_t    evT[PMG_IPC_WINDOW];   /* ring: host run-ahead throttle */
   uint64_t      nthrottle;
-  hipEvent_t    evF[2];                /* local: face planes of colour c done (face stream) */
   unsigned     *err_dev;               /* pinned host word (device-visible), set by a flag wait that gave up */
   unsigned     *xch_counter;           /* device: blocks of the push kernel that have finished */
   pmg_grid      g;
@@ -192,14 +192,9 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
   d->gcap             = 2 * d->plane > ((int64_t)1 << 19) ? 2 * d->plane : ((int64_t)1 << 19); /* two colour planes of the fine level, or 4 MB */
   const size_t bytes  = sizeof(double) * (size_t)(PMG_IPC_HDR + 4 * d->plane + 4 * d->gcap);
   /* fine-grained device memory: flag words and planes are written by a PEER device while this device's kernels poll
-     / read them, so the block must be coherent at system scope without relying on cache flushes at kernel boundaries
-     (what RCCL does for its peer-written buffers); plain hipMalloc memory if the allocation flag is not supported */
-  if (!st && hipExtMallocWithFlags((void **)&d->block, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-    (void)hipGetLastError();
-    d->block = NULL;
-    if (hipMalloc((void **)&d->block, bytes) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipMalloc of the halo receive block failed");
-  }
-  if (!st && hipMemset(d->block, 0, bytes) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+     and read them IN THE SAME KERNEL, so the block must be coherent at system scope without cache maintenance (what
+     RCCL uses for its peer-written buffers) */
+  if (!st && hipExtMallocWithFlags((void **)&d->block, bytes, hipDeviceMallocFinegrained) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipExtMallocWithFlags(fine-grained) of the halo receive block failed");
   d->recv  = d->block ? d->block + PMG_IPC_HDR : NULL;
   d->grecv = d->block ? d->recv + 4 * d->plane : NULL;
   if (!st && hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "stream creation failed");
@@ -209,12 +204,10 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
   if (!st && hipEventCreateWithFlags(&d->evS, hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   for (int q = 0; q < PMG_IPC_WINDOW && !st; ++q)
     if (hipEventCreateWithFlags(&d->evT[q], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
-  for (int c = 0; c < 2 && !st; ++c)
-    if (hipEventCreateWithFlags(&d->evF[c], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   if (!st && hipHostMalloc((void **)&d->err_dev, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipHostMalloc failed");
   if (!st) *d->err_dev = 0;
-  if (!st) st = pmg_dev_alloc((void **)&d->xch_counter, sizeof(unsigned));
-  if (!st && hipMemset(d->xch_counter, 0, sizeof(unsigned)) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+  if (!st) st = pmg_dev_alloc((void **)&d->xch_counter, 2 * sizeof(unsigned)); /* [0] generic exchange, [1] face wavefronts */
+  if (!st && hipMemset(d->xch_counter, 0, 2 * sizeof(unsigned)) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
   if (st) {
     pmg_dist_destroy(&d);
     return st;
@@ -314,75 +307,64 @@ static pmg_status ipc_check(pmg_dist d)
   return PMG_SUCCESS;
 }
 
-/* Two in-order streams per rank: the caller's stream s sweeps the INTERIOR planes of a colour, the face stream
-   f = cs runs  [wait for the neighbours' planes of the other colour] -> [face planes: read them from my block, store
-   the new planes into y and straight into the neighbours' blocks] -> [raise the neighbours' flags]  beside it; two
-   local events per colour tie them together (the faces of colour c read the interior of colour 1-c and vice versa).
-   The flag traffic and the small face kernel are hidden behind the interior sweep. */
+/* One launch per colour on the caller's stream.  The sweep kernel takes the face planes first: their wavefronts wait
+   (in the kernel) until the flag words say that the neighbours' planes of the other colour have landed in my block,
+   read them from there, store the new planes into y and straight into the neighbours' blocks, and the last face
+   wavefront raises the neighbours' flag words; meanwhile the remaining blocks sweep the interior planes.  The
+   neighbours' planes a colour needs were pushed one whole colour pass earlier, so nothing waits in steady state; no
+   second stream, no events, no host rendezvous.  Safe re-use of a receive slot: my faces of colour c overwrite the
+   neighbour's slot c only after its push of colour 1-c has arrived, which it issued after reading slot c. */
 static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, hipStream_t s)
 {
-  const int32_t nz = d->nz;
-  hipStream_t   f  = d->cs;
-  int64_t       own, ghost, n;
+  int64_t own, ghost, n;
   PMG_CALL(ipc_check(d));
-  PMG_HIP(hipEventRecord(d->evS, s));
-  PMG_HIP(hipStreamWaitEvent(f, d->evS, 0));
   for (int c = 0; c < 2; ++c) { /* the receive blocks hold nothing of this y yet: copy my boundary planes over */
     d->round[c] += 1;
     for (int side = 0; side < 2; ++side) {
       if ((side == 0 ? d->lo : d->hi) < 0) continue;
       PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
-      PMG_HIP(hipMemcpyAsync(d->peer_recv[side] + (int64_t)(c * 2 + (1 - side)) * d->plane, y + own, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, f));
+      PMG_HIP(hipMemcpyAsync(d->peer_recv[side] + (int64_t)(c * 2 + (1 - side)) * d->plane, y + own, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     }
-    PMG_CALL(ipc_signal_color(d, c, f));
+    PMG_CALL(ipc_signal_color(d, c, s));
   }
-  int      have_interior = 0; /* an interior sweep has been queued on s since the call began */
-  uint64_t ctr           = counter0;
+  uint64_t ctr = counter0;
   for (int32_t it = 0; it < its; ++it) {
     const int ndir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
     for (int q = 0; q < ndir; ++q) {
       const int dir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? (q == 0 ? PMG_SOR_FORWARD_SWEEP : PMG_SOR_BACKWARD_SWEEP) : sweep_type;
       for (int cc = 0; cc < 2; ++cc) {
-        const int c = dir == PMG_SOR_FORWARD_SWEEP ? cc : 1 - cc;
-        /* face stream */
-        if (have_interior) PMG_HIP(hipStreamWaitEvent(f, d->evT[(d->nthrottle - 1) % PMG_IPC_WINDOW], 0)); /* the last interior sweep (the other colour) */
-        PMG_CALL(ipc_wait_color(d, 1 - c, f));
+        const int      c = dir == PMG_SOR_FORWARD_SWEEP ? cc : 1 - cc;
         pmgk_grid_halo h;
-        h.glo = d->lo >= 0 ? d->recv + (int64_t)((1 - c) * 2 + 0) * d->plane : NULL;
-        h.ghi = d->hi >= 0 ? d->recv + (int64_t)((1 - c) * 2 + 1) * d->plane : NULL;
-        h.plo = d->lo >= 0 ? d->peer_recv[0] + (int64_t)(c * 2 + 1) * d->plane : NULL;
-        h.phi = d->hi >= 0 ? d->peer_recv[1] + (int64_t)(c * 2 + 0) * d->plane : NULL;
-        PMG_CALL(pmg_grid_sweep_color_faces_cvec(d->g, c, 1, scaled, seed, ctr, &h, b, y, f));
+        memset(&h, 0, sizeof h);
+        h.full = 1;
+        h.glo  = d->lo >= 0 ? d->recv + (int64_t)((1 - c) * 2 + 0) * d->plane : NULL;
+        h.ghi  = d->hi >= 0 ? d->recv + (int64_t)((1 - c) * 2 + 1) * d->plane : NULL;
+        h.plo  = d->lo >= 0 ? d->peer_recv[0] + (int64_t)(c * 2 + 1) * d->plane : NULL;
+        h.phi  = d->hi >= 0 ? d->peer_recv[1] + (int64_t)(c * 2 + 0) * d->plane : NULL;
+        h.wlo  = d->lo >= 0 ? flag_mine(d, (1 - c) * 2 + 0) : NULL; /* colour c reads colour 1-c across the slab faces */
+        h.whi  = d->hi >= 0 ? flag_mine(d, (1 - c) * 2 + 1) : NULL;
+        h.wval = d->round[1 - c];
         d->round[c] += 1;
-        PMG_CALL(ipc_signal_color(d, c, f));
-        PMG_HIP(hipEventRecord(d->evF[c], f));
-        /* compute stream: the interior of colour c reads the face planes of colour 1-c */
-        if (nz > 2) {
-          PMG_HIP(hipStreamWaitEvent(s, d->evF[1 - c], 0));
-          PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, 1, nz - 2, 1, scaled, seed, ctr, b, y, s));
-          const int slot = (int)(d->nthrottle % PMG_IPC_WINDOW);
-          if (d->nthrottle >= PMG_IPC_WINDOW) PMG_HIP(hipEventSynchronize(d->evT[slot])); /* bounded host run-ahead */
-          PMG_HIP(hipEventRecord(d->evT[slot], s));
-          d->nthrottle += 1;
-          have_interior = 1;
-        }
+        h.slo     = flag_peer(d, 0, c * 2 + 1);
+        h.shi     = flag_peer(d, 1, c * 2 + 0);
+        h.sval    = d->round[c];
+        h.counter = d->xch_counter + 1;
+        h.err     = d->err_dev;
+        PMG_CALL(pmg_grid_sweep_color_halo_cvec(d->g, c, 1, scaled, seed, ctr, &h, b, y, s));
       }
+      if ((ctr & 1) == 1) PMG_CALL(ipc_throttle(d, s)); /* an event every other sweep: each one costs a marker on the stream */
       ++ctr;
     }
   }
-  /* leave y self-contained: bring the latest neighbour planes into its own ghost planes (on the face stream), then
-     let the caller's stream see everything */
-  if (have_interior) PMG_HIP(hipStreamWaitEvent(f, d->evT[(d->nthrottle - 1) % PMG_IPC_WINDOW], 0));
+  /* leave y self-contained: bring the latest neighbour planes into its own ghost planes */
   for (int c = 0; c < 2; ++c) {
-    PMG_CALL(ipc_wait_color(d, c, f));
+    PMG_CALL(ipc_wait_color(d, c, s));
     for (int side = 0; side < 2; ++side) {
       if ((side == 0 ? d->lo : d->hi) < 0) continue;
       PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
-      PMG_HIP(hipMemcpyAsync(y + ghost, d->recv + (int64_t)(c * 2 + side) * d->plane, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, f));
+      PMG_HIP(hipMemcpyAsync(y + ghost, d->recv + (int64_t)(c * 2 + side) * d->plane, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     }
   }
-  PMG_HIP(hipEventRecord(d->evF[0], f));
-  PMG_HIP(hipStreamWaitEvent(s, d->evF[0], 0));
   if (counter_out) *counter_out = ctr;
   return PMG_SUCCESS;
 }
@@ -397,8 +379,6 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
       if (d->peer_block[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
     for (int q = 0; q < PMG_IPC_WINDOW; ++q)
       if (d->evT[q]) (void)hipEventDestroy(d->evT[q]);
-    for (int c = 0; c < 2; ++c)
-      if (d->evF[c]) (void)hipEventDestroy(d->evF[c]);
     if (d->err_dev) (void)hipHostFree(d->err_dev);
     pmg_dev_free(d->xch_counter);
     if (d->block) (void)hipFree(d->block);

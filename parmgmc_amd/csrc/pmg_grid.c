@@ -250,6 +250,19 @@ pmg_status pmg_grid_sweep_color_faces_cvec(pmg_grid g, int color, int noisy, int
   return PMG_SUCCESS;
 }
 
+/* ALL owned planes of one colour in one launch, face planes first, with the halo hand-shake inside the kernel
+   (halo->full must be set; see pmgk_grid_halo) */
+pmg_status pmg_grid_sweep_color_halo_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const pmgk_grid_halo *halo, const double *b, double *y, void *stream)
+{
+  PMG_CHECK(g && b && y && halo && halo->full, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(color == 0 || color == 1, PMG_ERR_ARG_OUTOFRANGE, "colour %d", color);
+  PMG_CHECK(!noisy || scaled || g->omega == 1.0, PMG_ERR_SUP, "the unscaled (sorgibbs) noise requires omega = 1 (src/pc_sorgibbs.c:94)");
+  pmgk_grid_op op;
+  pmg_grid_fill_op(g, &op, noisy != 0, scaled, seed, counter);
+  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, color, 0, g->L.nz, 1, halo, b, y, stream));
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_grid_halo_plane(pmg_grid g, int color, int side, int64_t *owned_offset, int64_t *ghost_offset, int64_t *count)
 {
   PMG_CHECK(g && owned_offset && ghost_offset && count, PMG_ERR_ARG_NULL, "null argument");

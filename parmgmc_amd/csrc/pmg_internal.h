@@ -38,6 +38,7 @@ pmg_status pmg_set_error(pmg_status code, const char *file, int line, const char
 
 static inline int pmg_sweep_type_ok(int t) { return t == PMG_SOR_FORWARD_SWEEP || t == PMG_SOR_BACKWARD_SWEEP || t == PMG_SOR_SYMMETRIC_SWEEP; }
 
+pmg_status pmg_grid_sweep_color_halo_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const pmgk_grid_halo *halo, const double *b, double *y, void *stream);
 pmg_status pmg_grid_sweep_color_faces_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const pmgk_grid_halo *halo, const double *b, double *y, void *stream);
 /* kernel-side description of a grid object (internal) */
 pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L);

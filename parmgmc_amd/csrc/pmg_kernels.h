@@ -42,10 +42,21 @@ typedef struct {
 } pmgk_grid_op;
 
 /* multi-GPU face planes: ghost planes of the OTHER colour to read (this rank's receive block) and destinations in
-   the z-neighbours' receive blocks (peer memory) for the freshly swept planes 0 / nz-1; null = unused */
+   the z-neighbours' receive blocks (peer memory) for the freshly swept planes 0 / nz-1; null = unused.
+   full != 0: ONE launch sweeps all owned planes of the colour, face planes first (blockIdx.z 0, 1 -> planes 0, nz-1);
+   the wavefronts of the face planes first wait until the flag words wlo / whi (this rank's block) have reached wval
+   -- the neighbours' planes of the other colour have landed -- and, after their stores, the LAST of them raises the
+   neighbours' flag words slo / shi to sval (counter: device word, zero between launches; err: set if a wait gives
+   up).  The receive block must be fine-grained memory: the ghost planes are read in the kernel that waited. */
 typedef struct {
   const double *glo, *ghi;
   double       *plo, *phi;
+  int32_t       full;
+  const uint64_t *wlo, *whi;
+  uint64_t       wval;
+  uint64_t      *slo, *shi;
+  uint64_t       sval;
+  unsigned      *counter, *err;
 } pmgk_grid_halo;
 /* sweeps the colour-`color` points of the kcount owned planes kbegin, kbegin+kstride, ...; halo may be NULL */
 int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, int kstride, const pmgk_grid_halo *halo, const double *b_cvec, double *y_cvec, void *stream);
