@@ -263,12 +263,6 @@ def main() -> None:
     from parmgmc_amd.dist import DistGridSampler
 
     n = args.n
-    smp = DistGridSampler(n, n, n, 10.0, rank, world, omega=args.omega, transport="ipc" if (share and world > 1) else None)
-    g = smp.grid
-    nat_b = torch.ones(g.n, dtype=torch.float64, device="cuda")
-    b = g.to_cvec(nat_b)
-    del nat_b
-    y = g.new_cvec()  # x0 = 0
     seed = 0xCAFE
 
     def barrier():
@@ -276,41 +270,72 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctr = smp.sample_cvec(b, y, args.warmup, seed, 0)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    ctr = smp.sample_cvec(b, y, args.steps, seed, ctr)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream is the one passed to the C-ABI)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    finite = bool(torch.isfinite(y).all().item())
-    # multi-GPU only, outside the timed region: rank 0 repeats the whole chain on ITS device alone and compares its slab
-    # bit for bit (the noise depends on global indices only, so the distributed chain must reproduce it exactly)
-    halo_check = None
-    if world > 1 and os.environ.get("PMG_BENCH_NO_HALO_CHECK") != "1":
-        try:
-            if rank == 0:
-                from parmgmc_amd import GridMCSOR
+    def measure(transport):
+        """warm-up + timed region on one halo transport; returns everything the JSON line needs"""
+        smp = DistGridSampler(n, n, n, 10.0, rank, world, omega=args.omega, transport=transport)
+        g = smp.grid
+        nat_b = torch.ones(g.n, dtype=torch.float64, device="cuda")
+        b = g.to_cvec(nat_b)
+        del nat_b
+        y = g.new_cvec()  # x0 = 0
+        ctr = smp.sample_cvec(b, y, args.warmup, seed, 0)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        ctr = smp.sample_cvec(b, y, args.steps, seed, ctr)
+        ev1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        smp.check()  # a device-side wait for a halo flag that gave up raises here
+        dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream is the one passed to the C-ABI)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        finite = bool(torch.isfinite(y).all().item())
+        # multi-GPU only, outside the timed region: rank 0 repeats the whole chain on ITS device alone and compares its
+        # slab bit for bit (the noise depends on global indices only, so the distributed chain must reproduce it exactly)
+        halo_check = None
+        if world > 1 and rank == 0 and os.environ.get("PMG_BENCH_NO_HALO_CHECK") != "1":
+            from parmgmc_amd import GridMCSOR
 
-                one = GridMCSOR(n, n, n, 10.0)
-                one.set_omega(args.omega)
-                ob = one.to_cvec(torch.ones(one.n, dtype=torch.float64, device="cuda"))
-                oy = one.new_cvec()
-                one.sample_cvec(ob, oy, args.warmup + args.steps, seed, 0, True)
-                mine = g.from_cvec(y)
-                ref = one.from_cvec(oy)[: mine.numel()]
-                halo_check = "bit-identical to the single-device chain (rank 0's slab)" if torch.equal(mine, ref) else f"MISMATCH vs the single-device chain: max abs diff {float((mine - ref).abs().max()):.3e}"
-                del one, ob, oy, mine, ref
-                torch.cuda.empty_cache()
+            one = GridMCSOR(n, n, n, 10.0)
+            one.set_omega(args.omega)
+            ob = one.to_cvec(torch.ones(one.n, dtype=torch.float64, device="cuda"))
+            oy = one.new_cvec()
+            one.sample_cvec(ob, oy, args.warmup + args.steps, seed, 0, True)
+            mine = g.from_cvec(y)
+            ref = one.from_cvec(oy)[: mine.numel()]
+            halo_check = "bit-identical to the single-device chain (rank 0's slab)" if torch.equal(mine, ref) else f"MISMATCH vs the single-device chain: max abs diff {float((mine - ref).abs().max()):.3e}"
+            del one, ob, oy, mine, ref
+            torch.cuda.empty_cache()
+        return dict(smp=smp, g=g, y=y, b=b, dt=float(tmax.item()), dev_ms=dev_ms, finite=finite, halo_check=halo_check)
+
+    # N > 1: the transports in order of preference; one that fails at run time (lost flag, wrong halo data) is dropped
+    # and the next one measured -- decided by rank 0's bit-for-bit check, agreed by all ranks
+    forced = os.environ.get("PMG_DIST_TRANSPORT") or ("ipc" if (share and world > 1) else None)
+    order = [forced] if (forced or world == 1) else ["ipc", "rccl", "torch"]
+    res, tried = None, []
+    for tr in order:
+        err = None
+        try:
+            res = measure(tr)
         except Exception as e:  # noqa: BLE001
-            halo_check = f"not run: {type(e).__name__}: {e}"
+            res, err = None, f"{type(e).__name__}: {e}"
+        good = res is not None and (res["halo_check"] is None or res["halo_check"].startswith("bit-identical"))
+        flag = torch.tensor([1 if good else 0], device="cpu" if (share or world == 1) else "cuda")
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        tried.append({"transport": tr, "actual": res["smp"].transport if res else None, "ok": bool(flag.item()), "error": err, "halo_check": res["halo_check"] if res else None})
+        if int(flag.item()) == 1:
+            break
+        if rank == 0:
+            print(f"[bench] halo transport {tr!r} rejected: {err or (res and res['halo_check'])}", file=sys.stderr, flush=True)
+        res = None
+        torch.cuda.empty_cache()
+    assert res is not None, f"no halo transport produced a valid chain: {tried}"
+    smp, g, y, b, dt, dev_ms, finite, halo_check = (res[k] for k in ("smp", "g", "y", "b", "dt", "dev_ms", "finite", "halo_check"))
+    used_transport = smp.transport
 
     if rank == 0:
         N_total = n * n * n
@@ -339,6 +364,8 @@ def main() -> None:
         }
         if halo_check is not None:
             out["halo_check"] = halo_check
+        if len(tried) > 1:
+            out["transports_tried"] = tried
     else:
         out = None
     # ---- secondary lines: never allowed to cost the headline line -------------------------------------------------
@@ -350,7 +377,7 @@ def main() -> None:
             print(json.dumps(out), flush=True)
 
     if not args.no_mgmc and os.environ.get("PMG_BENCH_NO_MGMC") != "1":
-        del b, y, smp, g
+        del b, y, smp, g, res
         torch.cuda.empty_cache()
 
         def bail():  # a collective that never completes must not swallow the measured headline
@@ -370,7 +397,7 @@ def main() -> None:
                         out[key] = fn()
                     except Exception as e:  # noqa: BLE001
                         out[key] = {"error": f"{type(e).__name__}: {e}"}
-            sec = mgmc_dist_secondary(rank, world, "ipc" if (share and world > 1) else None, share, args.mgmc_n, args.mgmc_levels)
+            sec = mgmc_dist_secondary(rank, world, used_transport if used_transport in ("ipc", "rccl") else None, share, args.mgmc_n, args.mgmc_levels)
             if rank == 0:
                 out["secondary_mgmc_dist"] = sec
         except Exception as e:  # noqa: BLE001

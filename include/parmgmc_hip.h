@@ -204,6 +204,9 @@ pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b_cvec, double *y_cvec
    every rank holds all blocks.  Collective: every rank makes the same sequence of calls. */
 pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo, const int64_t *nsend_lo, double *const *recv_lo, const int64_t *nrecv_lo, const double *const *send_hi, const int64_t *nsend_hi, double *const *recv_hi, const int64_t *nrecv_hi, void *stream);
 pmg_status pmg_dist_allgather(pmg_dist d, double *buf_dev, const int64_t *offsets, const int64_t *counts, void *stream);
+/* after synchronising the stream: PMG_ERR_LIB if a device-side wait for a halo flag gave up (lost or unreachable
+   neighbour); the object then fails every later call */
+pmg_status pmg_dist_check(pmg_dist d);
 /* rank / number of ranks / largest message (doubles) the generic exchange can carry */
 pmg_status pmg_dist_get_info(pmg_dist d, int32_t *rank, int32_t *nranks, int64_t *capacity);
 pmg_status pmg_dist_destroy(pmg_dist *d);

@@ -77,8 +77,10 @@ __device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, un
     unsigned long long spins = 0;
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1ull << 26)) {
-        if (err) atomicExch(err, 1u);
+      ++spins;
+      if ((spins & 0xFFFFu) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break; // somebody already gave up: do not stack timeouts
+      if (spins > (1ull << 25)) {
+        if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
     }

@@ -28,8 +28,10 @@ __global__ void flag_wait_kernel(const uint64_t *f0, const uint64_t *f1, uint64_
     unsigned long long spins = 0;
     while (__hip_atomic_load(f[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v[q]) {
       __builtin_amdgcn_s_sleep(32);
-      if (++spins > (1ull << 24)) {
-        if (err) atomicExch(err, 1u);
+      ++spins;
+      if ((spins & 0xFFFu) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return; // somebody already gave up
+      if (spins > (1ull << 24)) {
+        if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
       }
     }
@@ -77,8 +79,10 @@ __global__ __launch_bounds__(256) void xch_pull_kernel(pmgk_xch_args a, unsigned
       unsigned long long spins = 0;
       while (__hip_atomic_load(a.flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.value) {
         __builtin_amdgcn_s_sleep(32);
-        if (++spins > (1ull << 24)) {
-          if (err) atomicExch(err, 1u);
+        ++spins;
+        const bool gave_up = (spins & 0xFFFu) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (gave_up || spins > (1ull << 24)) {
+          if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           ok = 0;
           break;
         }

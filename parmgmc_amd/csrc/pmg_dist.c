@@ -505,6 +505,14 @@ pmg_status pmg_dist_allgather(pmg_dist d, double *buf, const int64_t *offsets, c
   return PMG_SUCCESS;
 }
 
+/* after the stream has been synchronised: did every halo flag arrive?  (a wait that gives up marks the object; all
+   later calls fail) */
+pmg_status pmg_dist_check(pmg_dist d)
+{
+  PMG_CHECK(d, PMG_ERR_ARG_NULL, "null dist object");
+  return d->transport == 1 ? ipc_check(d) : PMG_SUCCESS;
+}
+
 pmg_status pmg_dist_get_info(pmg_dist d, int32_t *rank, int32_t *nranks, int64_t *capacity)
 {
   PMG_CHECK(d, PMG_ERR_ARG_NULL, "null dist object");

@@ -140,6 +140,12 @@ class RcclSlabDriver:
         check(lib.pmg_dist_sample_cvec(self._h, _ptr(b), _ptr(y), its, int(scaled), sweep_type, seed, counter0, C.byref(out), _stream()))
         return out.value
 
+    def check(self):
+        """after torch.cuda.synchronize(): raises if a device-side wait for a halo flag gave up"""
+        from .capi import check, lib
+
+        check(lib.pmg_dist_check(self._h))
+
     def __del__(self):
         try:
             import ctypes as C
@@ -252,6 +258,11 @@ class DistGridSampler:
                     break
                 if rank == 0:
                     print(f"[parmgmc_amd] halo transport '{cand}' unavailable ({err if err else 'on another rank'}); trying the next one", flush=True)
+
+    def check(self):
+        """after torch.cuda.synchronize(): raises if the halo transport lost a neighbour"""
+        if self.rccl is not None:
+            self.rccl.check()
 
     def sample_cvec(self, b, y, its: int, seed: int, counter0: int = 0) -> int:
         if self.world == 1:
