@@ -25,6 +25,24 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ d2 ld2(const double *p) { return *reinterpret_cast<const d2 *>(p); }
 
+// 16-byte access to PEER-SHARED memory (the halo receive blocks) at system scope: two relaxed 64-bit atomics, which the
+// compiler emits as write-through / cache-bypassing accesses (sc0 sc1) -- the data is performed at the system's point
+// of coherence when the wavefront's s_waitcnt returns, which ordinary stores do not promise
+__device__ __forceinline__ d2 ld2_sys(const double *p)
+{
+  const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  d2                       v;
+  v.x = __longlong_as_double((long long)a);
+  v.y = __longlong_as_double((long long)b);
+  return v;
+}
+__device__ __forceinline__ void st2_sys(double *p, d2 v)
+{
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p) + 1, (unsigned long long)__double_as_longlong(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // wave-uniform double -> SGPR pair
 __device__ __forceinline__ double uniform(double v)
 {
@@ -121,8 +139,8 @@ __device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L,
   const d2     oS = ld2(yo - (hasS ? L.sx : 0));
   const d2     oN = ld2(yo + (hasN ? L.sx : 0));
   const int64_t inplane = (int64_t)j * L.sx + 2 * t; // offset inside one plane
-  const d2      oD = (HALO && k == 0 && halo.glo) ? ld2(halo.glo + inplane) : ld2(yo - (hasD ? L.sp : 0));
-  const d2      oU = (HALO && k == L.nz - 1 && halo.ghi) ? ld2(halo.ghi + inplane) : ld2(yo + (hasU ? L.sp : 0));
+  const d2      oD = (HALO && k == 0 && halo.glo) ? ld2_sys(halo.glo + inplane) : ld2(yo - (hasD ? L.sp : 0));
+  const d2      oU = (HALO && k == L.nz - 1 && halo.ghi) ? ld2_sys(halo.ghi + inplane) : ld2(yo + (hasU ? L.sp : 0));
   const d2     bb = ld2(b_own + line);
 
   const double L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
@@ -173,8 +191,8 @@ __device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L,
   const d2 out = {r0, v1 ? r1 : 0.0};
   *reinterpret_cast<d2 *>(y_own + line) = out;
   if (HALO) {
-    if (k == 0 && halo.plo) *reinterpret_cast<d2 *>(halo.plo + inplane) = out;
-    if (k == L.nz - 1 && halo.phi) *reinterpret_cast<d2 *>(halo.phi + inplane) = out;
+    if (k == 0 && halo.plo) st2_sys(halo.plo + inplane, out);
+    if (k == L.nz - 1 && halo.phi) st2_sys(halo.phi + inplane, out);
   }
 }
 
@@ -199,9 +217,9 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
     if (face_hi && halo.whi) wave_wait_flag(halo.whi, halo.wval, halo.err);
     grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, nbx, nby, bandw, k, ty, tab, halo, b_own, y_other, y_own);
     if (face_lo || face_hi) { // every block of a face plane reports; the last one tells the neighbours
-      // the peer stores went to fine-grained memory (write-through, not held in L2): waiting for their completion is
-      // all a wavefront has to do -- a system-scope release here would write the L2 back once per wavefront while
-      // the interior blocks are filling it (measured: 2.5x slower)
+      // the peer stores are system-scope write-through stores (st2_sys): waiting for their completion is all a
+      // wavefront has to do -- a system-scope release FENCE here would also write the whole L2 back, once per
+      // wavefront, while the interior blocks are filling it (measured: 2.5x slower)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads(); // one report per block: thousands of wavefronts on one counter would queue up at the L2
       if (threadIdx.x == 0 && threadIdx.y == 0) {

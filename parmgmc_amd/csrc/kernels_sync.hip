@@ -43,19 +43,26 @@ __global__ void flag_wait_kernel(const uint64_t *f0, const uint64_t *f1, uint64_
 //        finish raises the neighbours' flag words (every thread fences its stores at system scope first);
 // pull : every block waits for my flag words, then the segments are copied out of my slots.  The slots live in
 //        fine-grained memory, so the loads after the acquire see the peer's stores without a kernel boundary.
+// SRC_SHARED / DST_SHARED: that side lives in a peer-shared receive block and is accessed with system-scope relaxed
+// atomics (write-through / cache-bypassing), so that "my s_waitcnt returned" means "performed for the peer"
+template <bool SRC_SHARED, bool DST_SHARED>
 __device__ __forceinline__ void copy_segments(const pmgk_xch_args &a)
 {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
   for (int q = 0; q < a.nseg; ++q) {
-    const double *__restrict__ src = a.src[q];
-    double *__restrict__ dst       = a.dst[q];
-    for (int64_t i = tid; i < a.n[q]; i += nth) dst[i] = src[i];
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.src[q]);
+    unsigned long long       *dst = reinterpret_cast<unsigned long long *>(a.dst[q]);
+    for (int64_t i = tid; i < a.n[q]; i += nth) {
+      const unsigned long long v = SRC_SHARED ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : src[i];
+      if (DST_SHARED) __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else dst[i] = v;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void xch_push_kernel(pmgk_xch_args a, unsigned *counter)
 {
-  copy_segments(a);
+  copy_segments<false, true>(a);
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void xch_pull_kernel(pmgk_xch_args a, unsigned
   }
   __syncthreads();
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  copy_segments(a);
+  copy_segments<true, false>(a);
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }

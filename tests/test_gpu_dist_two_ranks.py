@@ -150,7 +150,8 @@ MG_DEFAULT = dict(scaled=False, omega=1.0, sweep=1, nu=1, coarse="cholsampler", 
     ((17, 17, 33), 4, 3, {"env": {"PMG_MG_REPLICATE_BELOW": "400"}}),                      # distributed class-stencil levels, uneven slabs
     ((33, 17, 33), 4, 4, {"env": {"PMG_MG_REPLICATE_BELOW": "2000"}, "scaled": True, "omega": 1.2, "sweep": 3, "nu": 2, "coarse": "gibbs", "coarse_its": 2}),
     ((17, 9, 33), 3, 2, {"env": {"PMG_MG_REPLICATE_BELOW": "100"}, "literal": True, "sweep": 2, "scaled": True}),
-], ids=["replicated", "slab_levels_3ranks", "symmetric_gibbs_coarse_4ranks", "literal_backward"])
+    ((9, 9, 33), 4, 5, {"env": {"PMG_MG_REPLICATE_BELOW": "50"}, "scaled": True, "sweep": 3}),  # three distributed levels; on the 9-plane level the ranks own 2,2,2,1,2 planes (5 ranks + this process = the box's limit of 6 GPU processes)
+], ids=["replicated", "slab_levels_3ranks", "symmetric_gibbs_coarse_4ranks", "literal_backward", "one_plane_per_rank_5ranks"])
 def test_distributed_vcycle_reproduces_the_single_device_chain(grid, levels, world, opts):
     """z-slab MGMC (pmg_mgmc_create_dmda_slab) with `world` ranks sharing the one GPU over the ipc transport: sweeps
     with per-phase halos, residual halo + restriction, all-gather into the replicated coarse part, prolongation onto
