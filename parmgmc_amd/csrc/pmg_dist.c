@@ -285,21 +285,6 @@ static pmg_status ipc_throttle(pmg_dist d, hipStream_t s)
 static uint64_t *flag_mine(pmg_dist d, int idx) { return (uint64_t *)d->block + idx; }
 static uint64_t *flag_peer(pmg_dist d, int side, int idx) { return (side == 0 ? d->lo : d->hi) >= 0 ? (uint64_t *)d->peer_block[side] + idx : NULL; }
 
-/* on `st`: tell both neighbours that my colour-c planes of round round[c] are in their blocks (my low plane sits in
-   the low neighbour's HIGH slot and vice versa) */
-static pmg_status ipc_signal_color(pmg_dist d, int c, hipStream_t st)
-{
-  PMG_KERNEL(pmgk_flag_signal(flag_peer(d, 0, c * 2 + 1), d->round[c], flag_peer(d, 1, c * 2 + 0), d->round[c], st));
-  return PMG_SUCCESS;
-}
-
-/* on `st`: wait until both neighbours' colour-c planes of round round[c] have landed in my block */
-static pmg_status ipc_wait_color(pmg_dist d, int c, hipStream_t st)
-{
-  PMG_KERNEL(pmgk_flag_wait(d->lo >= 0 ? flag_mine(d, c * 2 + 0) : NULL, d->round[c], d->hi >= 0 ? flag_mine(d, c * 2 + 1) : NULL, d->round[c], d->err_dev, st));
-  return PMG_SUCCESS;
-}
-
 /* a flag wait of an EARLIER round gave up (lost neighbour): fail the next call instead of computing on */
 static pmg_status ipc_check(pmg_dist d)
 {
@@ -318,14 +303,22 @@ static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its
 {
   int64_t own, ghost, n;
   PMG_CALL(ipc_check(d));
-  for (int c = 0; c < 2; ++c) { /* the receive blocks hold nothing of this y yet: copy my boundary planes over */
-    d->round[c] += 1;
-    for (int side = 0; side < 2; ++side) {
-      if ((side == 0 ? d->lo : d->hi) < 0) continue;
-      PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
-      PMG_HIP(hipMemcpyAsync(d->peer_recv[side] + (int64_t)(c * 2 + (1 - side)) * d->plane, y + own, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+  { /* the receive blocks hold nothing of this y yet: my boundary planes of both colours go over in one launch */
+    pmgk_xch_args push;
+    memset(&push, 0, sizeof push);
+    for (int c = 0; c < 2; ++c) {
+      d->round[c] += 1;
+      for (int side = 0; side < 2; ++side) {
+        if ((side == 0 ? d->lo : d->hi) < 0) continue;
+        PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
+        push.src[push.nseg]    = y + own;
+        push.dst[push.nseg]    = d->peer_recv[side] + (int64_t)(c * 2 + (1 - side)) * d->plane;
+        push.n[push.nseg++]    = n;
+        push.flag[c * 2 + side]  = flag_peer(d, side, c * 2 + (1 - side));
+        push.value[c * 2 + side] = d->round[c];
+      }
     }
-    PMG_CALL(ipc_signal_color(d, c, s));
+    PMG_KERNEL(pmgk_xch_push(&push, d->xch_counter, s));
   }
   uint64_t ctr = counter0;
   for (int32_t it = 0; it < its; ++it) {
@@ -356,14 +349,20 @@ static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its
       ++ctr;
     }
   }
-  /* leave y self-contained: bring the latest neighbour planes into its own ghost planes */
-  for (int c = 0; c < 2; ++c) {
-    PMG_CALL(ipc_wait_color(d, c, s));
-    for (int side = 0; side < 2; ++side) {
-      if ((side == 0 ? d->lo : d->hi) < 0) continue;
-      PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
-      PMG_HIP(hipMemcpyAsync(y + ghost, d->recv + (int64_t)(c * 2 + side) * d->plane, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    }
+  { /* leave y self-contained: the latest neighbour planes go into its own ghost planes, one launch */
+    pmgk_xch_args pull;
+    memset(&pull, 0, sizeof pull);
+    for (int c = 0; c < 2; ++c)
+      for (int side = 0; side < 2; ++side) {
+        if ((side == 0 ? d->lo : d->hi) < 0) continue;
+        PMG_CALL(pmg_grid_halo_plane(d->g, c, side, &own, &ghost, &n));
+        pull.src[pull.nseg]      = d->recv + (int64_t)(c * 2 + side) * d->plane;
+        pull.dst[pull.nseg]      = y + ghost;
+        pull.n[pull.nseg++]      = n;
+        pull.flag[c * 2 + side]  = flag_mine(d, c * 2 + side);
+        pull.value[c * 2 + side] = d->round[c];
+      }
+    PMG_KERNEL(pmgk_xch_pull(&pull, d->err_dev, s));
   }
   if (counter_out) *counter_out = ctr;
   return PMG_SUCCESS;
@@ -441,7 +440,6 @@ pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo,
   pmgk_xch_args push, pull;
   memset(&push, 0, sizeof push);
   memset(&pull, 0, sizeof pull);
-  push.value = pull.value = d->ground;
   for (int side = 0; side < 2; ++side) {
     if (nb[side] < 0) continue;
     int64_t off = 0, roff = 0;
@@ -460,8 +458,9 @@ pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo,
       off += ns[side][q];
       roff += nr[side][q];
     }
-    push.flag[side] = flag_peer(d, side, 4 + (1 - side));
-    pull.flag[side] = flag_mine(d, 4 + side);
+    push.flag[side]  = flag_peer(d, side, 4 + (1 - side));
+    pull.flag[side]  = flag_mine(d, 4 + side);
+    push.value[side] = pull.value[side] = d->ground;
   }
   PMG_KERNEL(pmgk_xch_push(&push, d->xch_counter, s));
   PMG_KERNEL(pmgk_xch_pull(&pull, d->err_dev, s));

@@ -135,20 +135,16 @@ int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, 
 int pmgk_lrc_axpy_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *coef, double sign, double *v, double *save, void *stream);
 int pmgk_lrc_scatter_rows(int64_t ns, const int64_t *rows, const double *save, double *v, void *stream);
 int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);
-/* flag words of the "ipc" halo transport: raise up to two words (system-scope release) / wait until up to two words have
-   reached their values (one wave, sleeps between polls, *err = 1 after ~10 s); null pointers are skipped */
-int pmgk_flag_signal(uint64_t *p0, uint64_t v0, uint64_t *p1, uint64_t v1, void *stream);
-int pmgk_flag_wait(const uint64_t *f0, uint64_t v0, const uint64_t *f1, uint64_t v1, unsigned *err, void *stream);
-/* generic exchange in two launches: push = copy segments (src -> dst, dst in the neighbours' slots) then raise
-   flag[0..1] to `value` from the last block; pull = wait for flag[0..1] >= value, then copy segments out of my slots */
+/* exchange in two launches: push = copy segments (src -> dst, dst in the neighbours' slots) then raise flag[q] to
+   value[q] from the last block; pull = wait for flag[q] >= value[q], then copy segments out of my slots */
 #define PMGK_XCH_MAXSEG 8
 typedef struct {
   int           nseg;
   const double *src[PMGK_XCH_MAXSEG];
   double       *dst[PMGK_XCH_MAXSEG];
   int64_t       n[PMGK_XCH_MAXSEG];
-  uint64_t     *flag[2];
-  uint64_t      value;
+  uint64_t     *flag[4]; /* null entries are skipped */
+  uint64_t      value[4];
 } pmgk_xch_args;
 int pmgk_xch_push(const pmgk_xch_args *a, unsigned *counter, void *stream);
 int pmgk_xch_pull(const pmgk_xch_args *a, unsigned *err, void *stream);
