@@ -110,6 +110,13 @@ pmg_status pmg_mcsor_from_layout(pmg_mcsor mc, const double *lay_dev, double *na
 pmg_status pmg_mcsor_apply_layout(pmg_mcsor mc, const double *b_lay, double *y_lay, void *stream);
 pmg_status pmg_mcsor_sample_layout(pmg_mcsor mc, const double *b_lay, double *y_lay, int32_t its, int scaled, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
 pmg_status pmg_mcsor_residual_layout(pmg_mcsor mc, const double *b_lay, const double *y_lay, double *r_lay, void *stream);
+/* Building blocks of the ROW-BLOCK distributed sampler (MCSORApply_MPIAIJ, src/mc_sor.c:298-381: for every colour,
+   update the ghost values, then sweep the colour's rows): a rank holds its rows with the off-process columns appended
+   as ghost rows (identity rows in an extra, never swept colour); the caller moves ghost values between the per-colour
+   sweeps (parmgmc_amd/dist.py: DistMCSOR over torch.distributed).  row0 = global index of local row 0, so that the
+   noise is that of the global row and the chain is the single-process chain bit for bit. */
+pmg_status pmg_mcsor_set_noise_row_offset(pmg_mcsor mc, int64_t row0);
+pmg_status pmg_mcsor_sweep_color_layout(pmg_mcsor mc, int32_t color, int noisy, int scaled, uint64_t seed, uint64_t sweep, const double *b_layout_dev, double *y_layout_dev, void *stream);
 /* MATLRC operators A + B S B^T (MCSORSetUp's LRC branch, src/mc_sor.c:572-595; MCSORBuildLRCCorrection :480-544):
    B is n x k column-major on the host in the matrix's row numbering, S the k diagonal entries of Sigma^-1.
    Call after pmg_mcsor_setup (uses the current omega).  Afterwards every directional sweep is followed by

@@ -91,6 +91,8 @@ _sig = {
     "pmg_mcsor_apply_layout": (_int, [_vp, _vp, _vp, _vp]),
     "pmg_mcsor_sample_layout": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_mcsor_residual_layout": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pmg_mcsor_set_noise_row_offset": (_int, [_vp, C.c_int64]),
+    "pmg_mcsor_sweep_color_layout": (_int, [_vp, _i32, _int, _int, _u64, _u64, _vp, _vp, _vp]),
     "pmg_mcsor_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_mcsor_destroy": (_int, [C.POINTER(_vp)]),
     "pmg_grid_create": (_int, [_i32, _i32, _i32, _i32, _i32, _dbl, C.POINTER(_vp)]),

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void sell_color_sweep_kernel(pmgk_sell S, int 
   double        sum = b[row];
   if (NOISY) {
     // row stream: entries (2q, 2q+1) of the ORIGINAL numbering share one Box-Muller pair
-    const uint32_t uorg = org < 0 ? 0u : (uint32_t)org;
+    const uint32_t uorg = org < 0 ? 0u : (uint32_t)(S.noise_row0 + org); // global row of a row block
     double         z0, z1;
     pmg::normal_pair(uorg >> 1, 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
     const double xi = (uorg & 1u) ? z1 : z0;

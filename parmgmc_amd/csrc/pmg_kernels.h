@@ -80,6 +80,7 @@ typedef struct {
   const double  *sqrtdiag; /* [ld] device */
   const double  *diag;     /* [ld] device */
   const int32_t *orig;     /* [ld] device: original row of permuted row, -1 in pad rows */
+  int64_t        noise_row0; /* the noise of original row r is the row stream of noise_row0 + r (row block of a distributed matrix) */
 } pmgk_sell;
 
 int pmgk_sell_color_sweep(const pmgk_sell *S, int slice0, int nsl, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream);

@@ -32,6 +32,7 @@ struct pmg_mcsor_s {
   double  *idiag_dev, *sqrtd_dev, *sqrtd_scaled_dev;
   double  *b_p, *y_p, *r_p; /* permuted scratch vectors */
   pmg_lrc  lrc;             /* MATLRC: rank-k update B S B^T (src/mc_sor.c:572-595) */
+  int64_t  noise_row0;      /* global row of local row 0 (row block of a distributed matrix) */
 };
 
 /* --- colouring rules -------------------------------------------------------------------------------- */
@@ -289,6 +290,7 @@ pmg_status pmg_mcsor_setup(pmg_mcsor mc)
 
   mc->S.n       = n;
   mc->S.ld      = ld;
+  mc->S.noise_row0 = mc->noise_row0;
   mc->S.nslices = nslices;
   st            = pmg_dev_upload((void **)&mc->S.soff, soff, sizeof(int64_t) * ((size_t)nslices + 1));
   if (!st) st = pmg_dev_upload((void **)&mc->S.swidth, swidth, sizeof(int32_t) * (size_t)nslices);
@@ -425,6 +427,30 @@ pmg_status pmg_mcsor_sample(pmg_mcsor mc, const double *b, double *y, int32_t it
   }
   PMG_KERNEL(pmgk_permute_out(mc->S.ld, mc->S.orig, mc->y_p, y, stream));
   if (counter_out) *counter_out = ctr;
+  return PMG_SUCCESS;
+}
+
+/* ---- building blocks of the row-block distributed sampler (MCSORApply_MPIAIJ, src/mc_sor.c:298-381: per colour, ghost
+   update then the colour's rows) ---- */
+pmg_status pmg_mcsor_set_noise_row_offset(pmg_mcsor mc, int64_t row0)
+{
+  PMG_CHECK(mc, PMG_ERR_ARG_NULL, "null MCSOR");
+  PMG_CHECK(row0 >= 0, PMG_ERR_ARG_OUTOFRANGE, "row offset %lld", (long long)row0);
+  mc->S.noise_row0 = row0;
+  mc->noise_row0   = row0;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mcsor_sweep_color_layout(pmg_mcsor mc, int32_t color, int noisy, int scaled, uint64_t seed, uint64_t sweep, const double *b_lay, double *y_lay, void *stream)
+{
+  PMG_CHECK(mc && b_lay && y_lay, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CALL(mcsor_ready(mc));
+  PMG_CHECK(color >= 0 && color < mc->ncolors, PMG_ERR_ARG_OUTOFRANGE, "colour %d of %d", color, mc->ncolors);
+  PMG_CHECK(!mc->lrc, PMG_ERR_SUP, "per-colour sweeps do not carry the low-rank repair");
+  PMG_CHECK(!noisy || scaled || mc->omega == 1.0, PMG_ERR_SUP, "the unscaled (sorgibbs) noise requires omega = 1 (src/pc_sorgibbs.c:94)");
+  pmgk_sell S = mc->S;
+  S.sqrtdiag  = scaled ? mc->sqrtd_scaled_dev : mc->sqrtd_dev;
+  PMG_KERNEL(pmgk_sell_color_sweep(&S, mc->cslice[color], mc->cslice[color + 1] - mc->cslice[color], mc->omega, noisy, seed, sweep, b_lay, y_lay, stream));
   return PMG_SUCCESS;
 }
 

@@ -313,3 +313,123 @@ class DistMGMC:
     def destroy(self):
         self.mg.destroy()  # before the transport and the grid it borrows
         self.grid_sampler = None
+
+
+class DistMCSOR:
+    """mcgibbs / sorgibbs sampler for an assembled MATAIJ matrix distributed by ROW BLOCKS over `world` ranks
+    (reference MCSORApply_MPIAIJ, src/mc_sor.c:298-381: for every colour, update the ghost values, then sweep the
+    colour's rows; scatter plan as MatCreateScatters :152-214, de-duplicated per ghost column).
+
+    This rank owns rows [row0, row1) of the global matrix: rowptr / colidx / vals are its rows with GLOBAL column
+    indices, colors its rows' entries of a globally valid distance-1 colouring (ncolors colours).  The off-process
+    columns become ghost rows (identity rows in an extra colour that is never swept) of a local sliced-ELL operator;
+    the per-colour sweeps run on the device (pmg_mcsor_sweep_color_layout), the ghost values travel through
+    torch.distributed point-to-point messages between them.  Noise is keyed on the global row, entries keep the order
+    of the global CSR row: the chain is the single-process chain bit for bit."""
+
+    def __init__(self, rowptr, colidx, vals, row0, row1, n_global, colors, ncolors, rank, world, omega=1.0, sweep_type=SOR_FORWARD_SWEEP, scaled=True, group=None):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+
+        from .wrappers import MCSOR
+
+        self.rank, self.world, self.group = rank, world, group
+        self.row0, self.row1, self.nloc, self.ncolors = row0, row1, row1 - row0, ncolors
+        self.sweep_type, self.scaled = sweep_type, scaled
+        rp = np.asarray(rowptr, np.int64)
+        ci = np.asarray(colidx, np.int64)
+        v = np.asarray(vals, np.float64)
+        assert len(rp) == self.nloc + 1 and len(colors) == self.nloc
+        is_ghost = (ci < row0) | (ci >= row1)
+        self.ghosts = np.unique(ci[is_ghost])  # sorted global ids of the ghost columns
+        ng = len(self.ghosts)
+        loc = np.where(is_ghost, self.nloc + np.searchsorted(self.ghosts, ci), ci - row0)
+        # local operator: my rows (entries in the order of the global CSR row) + one identity row per ghost column
+        rp2 = np.concatenate([rp, rp[-1] + 1 + np.arange(ng)]).astype(np.int32)
+        ci2 = np.concatenate([loc, self.nloc + np.arange(ng)]).astype(np.int32)
+        v2 = np.concatenate([v, np.ones(ng)])
+        col2 = np.concatenate([np.asarray(colors, np.int32), np.full(ng, ncolors, np.int32)])
+        self.mc = MCSOR(rp2, ci2, v2, user_colors=col2)
+        self.mc.set_omega(omega)
+        self.mc.setup()
+        self.mc.set_noise_row_offset(row0)
+        pos = self.mc.get_layout().astype(np.int64)
+        self.ld = self.mc.layout_len()
+        self.pos_local = torch.as_tensor(pos[: self.nloc], device="cuda")
+        # --- scatter plan: who owns my ghosts, what do the others need from me, in which colour does it change ---
+        ranges = [None] * world
+        dist.all_gather_object(ranges, (row0, row1), group=group)
+        starts = np.array([r[0] for r in ranges] + [n_global])
+        owner = np.searchsorted(starts, self.ghosts, side="right") - 1
+        want = [self.ghosts[owner == p] for p in range(world)]  # global rows I need from rank p
+        asked = [None] * world
+        dist.all_gather_object(asked, want, group=group)  # asked[q][p] = rows rank q needs from rank p
+        mycol = np.asarray(colors, np.int64)
+        reply = [mycol[np.asarray(asked[q][rank], np.int64) - row0] if q != rank else None for q in range(world)]
+        replies = [None] * world
+        dist.all_gather_object(replies, reply, group=group)  # replies[p][q] = colours of the rows q asked from p
+        self.send, self.recv = [], []  # per colour: list of (peer, positions in my layout vector)
+        for c in range(ncolors):
+            snd, rcv = [], []
+            for p in range(world):
+                if p == rank:
+                    continue
+                rows_p = np.asarray(asked[p][rank], np.int64)  # what p needs from me
+                sel = rows_p[mycol[rows_p - row0] == c] if len(rows_p) else rows_p
+                if len(sel):
+                    snd.append((p, torch.as_tensor(pos[sel - row0], device="cuda")))
+                g = want[p]
+                selg = g[np.asarray(replies[p][rank]) == c] if len(g) else g
+                if len(selg):
+                    rcv.append((p, torch.as_tensor(pos[self.nloc + np.searchsorted(self.ghosts, selg)], device="cuda")))
+            self.send.append(snd)
+            self.recv.append(rcv)
+        self._staged = dist.get_backend(group) != "nccl"  # gloo: through host memory
+
+    def new_layout(self):
+        import torch
+
+        return torch.zeros(self.ld, dtype=torch.float64, device="cuda")
+
+    def to_layout(self, nat_local, out=None):
+        out = self.new_layout() if out is None else out
+        out[self.pos_local] = nat_local
+        return out
+
+    def from_layout(self, lay):
+        return lay[self.pos_local]
+
+    def exchange(self, y, color: int):
+        """ghost update for the rows of one colour (VecScatterBegin/End of src/mc_sor.c:318-319)"""
+        import torch
+        import torch.distributed as dist
+
+        ops, bufs = [], []
+        for p, idx in self.send[color]:
+            t = y[idx]
+            t = t.cpu() if self._staged else t
+            ops.append(dist.P2POp(dist.isend, t, p, self.group))
+        for p, idx in self.recv[color]:
+            t = torch.empty(len(idx), dtype=torch.float64, device="cpu" if self._staged else "cuda")
+            bufs.append((idx, t))
+            ops.append(dist.P2POp(dist.irecv, t, p, self.group))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        for idx, t in bufs:
+            y[idx] = t.cuda() if self._staged else t
+
+    def sample_layout(self, b, y, its: int, seed: int, counter0: int = 0) -> int:
+        """`its` samples on layout vectors (b: my rows filled, y: my rows filled; ghost entries are refreshed here)"""
+        for c in range(self.ncolors):
+            self.exchange(y, c)
+        ctr = counter0
+        for _ in range(its):
+            for direction in ((SOR_FORWARD_SWEEP, SOR_BACKWARD_SWEEP) if self.sweep_type == SOR_SYMMETRIC_SWEEP else (self.sweep_type,)):
+                order = range(self.ncolors) if direction == SOR_FORWARD_SWEEP else range(self.ncolors - 1, -1, -1)
+                for c in order:
+                    self.mc.sweep_color_layout(c, b, y, True, self.scaled, seed, ctr)
+                    self.exchange(y, c)
+                ctr += 1
+        return ctr

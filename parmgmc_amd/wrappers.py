@@ -81,6 +81,24 @@ class MCSOR:
     def residual(self, b, y, r):
         check(lib.pmg_mcsor_residual(self._h, _ptr(b), _ptr(y), _ptr(r), _stream()))
 
+    # --- storage layout and per-colour sweeps (building blocks of the row-block distributed sampler) ---
+    def layout_len(self) -> int:
+        n = C.c_int32()
+        check(lib.pmg_mcsor_layout_len(self._h, C.byref(n)))
+        return n.value
+
+    def get_layout(self) -> np.ndarray:
+        """position of every row in the library's storage layout"""
+        out = np.zeros(max(self.n, 1), np.int32)
+        check(lib.pmg_mcsor_get_layout(self._h, out.ctypes.data))
+        return out[: self.n]
+
+    def set_noise_row_offset(self, row0: int):
+        check(lib.pmg_mcsor_set_noise_row_offset(self._h, row0))
+
+    def sweep_color_layout(self, color: int, b_lay, y_lay, noisy: bool = True, scaled: bool = True, seed: int = 0, counter: int = 0):
+        check(lib.pmg_mcsor_sweep_color_layout(self._h, color, int(noisy), int(scaled), seed, counter, _ptr(b_lay), _ptr(y_lay), _stream()))
+
     def set_lowrank(self, B, S):
         """MATLRC A + B diag(S) B^T: B (n x k), S (k) host arrays (reference src/mc_sor.c:572-595)."""
         B = np.asfortranarray(B, dtype=np.float64)
