@@ -363,6 +363,39 @@ void orc_gibbs_sample_serial(int n, const int32_t *rowptr, const int32_t *colidx
   for (int r = 0; r < n; ++r) orc_row_update(r, rowptr, colidx, vals, diagptr, idiag, omega, w, y);
 }
 
+/* The same sample with a distance-1 colouring on ALL host cores (OpenMP where the library is built with -fopenmp;
+   plain loops otherwise): rows of one colour are independent (reference src/mc_sor.c:256-271 over the rows of an IS),
+   so each colour is one parallel loop -- what the reference does with one MPI rank per core.  Used by bench.py as the
+   second CPU baseline (cores = the threads OpenMP reports). */
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+  extern int omp_get_max_threads(void);
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+void orc_gibbs_sample_colored_parallel(int n, int ncolors, const int32_t *colorptr, const int32_t *colorrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, const int32_t *diagptr, const double *idiag, const double *sqrtdiag, double omega, const double *b, double *y, double *w, uint64_t seed, uint64_t sweep)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  const int64_t  npairs = ((int64_t)n + 1) / 2;
+#pragma omp parallel for schedule(static)
+  for (int64_t q = 0; q < npairs; ++q) { /* orc_noise_rows + the two RHS passes, fused per pair */
+    const uint32_t ctr[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)sweep, (uint32_t)(sweep >> 32)};
+    double         z[2];
+    orc_normal_pair(ctr, key, z);
+    const int64_t r = 2 * q;
+    w[r]            = z[0] * sqrtdiag[r] + b[r];
+    if (r + 1 < n) w[r + 1] = z[1] * sqrtdiag[r + 1] + b[r + 1];
+  }
+  for (int c = 0; c < ncolors; ++c) {
+#pragma omp parallel for schedule(static)
+    for (int32_t p = colorptr[c]; p < colorptr[c + 1]; ++p) orc_row_update(colorrows[p], rowptr, colidx, vals, diagptr, idiag, omega, w, y);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Coarse exact sampler
  * ---------------------------------------------------------------------------------------- */

@@ -156,3 +156,19 @@ def test_golden_files_match_oracle():
     from scipy import stats
 
     assert stats.kstest(xi, "norm").pvalue > 1e-3
+
+
+def test_parallel_coloured_sample_equals_the_serial_restatement():
+    """the all-cores CPU baseline of bench.py (one OpenMP loop per colour) is the same chain as the scalar oracle"""
+    A = O.shifted_laplace(11, 7, 5, 2.0)
+    n = A.n
+    cols = O.coloring_redblack(11, 7, 5)
+    nc, cptr, crows = O.color_lists(cols)
+    dp, idg, sd = O.diag_pointers(A), O.idiag(A, 1.0), O.sqrtdiag(A, 1.0, True)
+    rng = np.random.default_rng(0)
+    b, y = rng.standard_normal(n), rng.standard_normal(n)
+    want = O.gibbs_samples(A, cols, b, y, 1, lambda d: O.noise_rows(n, 9, 4), 1.0, O.SOR_FORWARD, True)
+    for native in (False, True):
+        got, w = y.copy(), np.zeros(n)
+        O.lib(native).orc_gibbs_sample_colored_parallel(n, nc, cptr, crows, A.rowptr, A.colidx, A.vals, dp, idg, sd, 1.0, b, got, w, 9, 4)
+        assert np.array_equal(got, want)
