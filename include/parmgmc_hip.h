@@ -197,6 +197,9 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
 pmg_status pmg_dist_ipc_blob_bytes(int32_t *bytes);
 pmg_status pmg_dist_ipc_export(pmg_dist d, void *blob);
 pmg_status pmg_dist_ipc_connect(pmg_dist d, const void *blob_lo, const void *blob_hi);
+/* optional, after pmg_dist_ipc_connect: map every rank's block (blobs[0..nranks-1], own entry ignored) so that
+   pmg_dist_allgather is one step instead of nranks - 1 rounds along the chain of neighbours */
+pmg_status pmg_dist_ipc_connect_all(pmg_dist d, const void *const *blobs);
 /* single rank as its own z-neighbour for the halo only (one-GPU timing / smoke test of the schedule) */
 pmg_status pmg_dist_ipc_connect_loopback(pmg_dist d);
 /* `its` samples of the sorgibbs (scaled = 0) / mcgibbs (scaled = 1) chain on this rank's slab, cvec vectors,

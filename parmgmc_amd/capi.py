@@ -139,6 +139,7 @@ _sig = {
     "pmg_mgmc_create_dmda_slab": (_int, [_i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, C.POINTER(_vp)]),
     "pmg_dist_exchange": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmg_dist_allgather": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pmg_dist_ipc_connect_all": (_int, [_vp, _vp]),
     "pmg_dist_check": (_int, [_vp]),
     "pmg_dist_get_info": (_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_int64)]),
     "pmg_mgmc_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),

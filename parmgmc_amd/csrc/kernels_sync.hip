@@ -70,9 +70,58 @@ __global__ __launch_bounds__(256) void xch_pull_kernel(pmgk_xch_args a, unsigned
   copy_segments<true, false>(a);
 }
 
+// ---- all-gather over all-peer mappings ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void allgather_push_kernel(int nranks, int me, const double *__restrict__ src, int64_t n, double *const *__restrict__ dst, int64_t dst_off, uint64_t *const *__restrict__ flag, uint64_t value, unsigned *counter)
+{
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  const unsigned long long *s = reinterpret_cast<const unsigned long long *>(src);
+  for (int p = 0; p < nranks; ++p) {
+    if (p == me || !dst[p]) continue;
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(dst[p] + dst_off);
+    for (int64_t i = tid; i < n; i += nth) __hip_atomic_store(d + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(counter, 1u) == gridDim.x - 1) {
+    *counter = 0;
+    __threadfence_system();
+    for (int p = 0; p < nranks; ++p)
+      if (p != me && flag[p]) __hip_atomic_store(flag[p], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ void allgather_wait_kernel(int nranks, int me, const uint64_t *myflags, uint64_t value, unsigned *err)
+{
+  const int p = threadIdx.x;
+  if (p >= nranks || p == me) return;
+  unsigned long long spins = 0;
+  while (__hip_atomic_load(myflags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
+    __builtin_amdgcn_s_sleep(32);
+    ++spins;
+    const bool gave_up = (spins & 0xFFFu) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (gave_up || spins > (1ull << 24)) {
+      if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
+
+extern "C" int pmgk_allgather_push(int nranks, int me, const double *src, int64_t n, double *const *dst_dev, int64_t dst_off, uint64_t *const *flag_dev, uint64_t value, unsigned *counter, void *stream)
+{
+  const int nb = n > 0 ? (int)((n + 4095) / 4096 < 64 ? (n + 4095) / 4096 : 64) : 1;
+  hipLaunchKernelGGL(allgather_push_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, nranks, me, src, n, dst_dev, dst_off, flag_dev, value, counter);
+  return launch_status();
+}
+
+extern "C" int pmgk_allgather_wait(int nranks, int me, const uint64_t *myflags, uint64_t value, unsigned *err, void *stream)
+{
+  hipLaunchKernelGGL(allgather_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nranks, me, myflags, value, err);
+  return launch_status();
+}
 
 extern "C" int pmgk_xch_push(const pmgk_xch_args *a, unsigned *counter, void *stream)
 {

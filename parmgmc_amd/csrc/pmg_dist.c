@@ -100,6 +100,13 @@ struct pmg_dist_s {
   uint64_t      nthrottle;
   unsigned     *err_dev;               /* pinned host word (device-visible), set by a flag wait that gave up */
   unsigned     *xch_counter;           /* device: blocks of the push kernel that have finished */
+  /* all-peer mappings (optional, pmg_dist_ipc_connect_all): single-step all-gather.  Every block has, behind the
+     generic slots, two gather areas (parity) of gcap doubles; flag word 8 + src announces rank src's block */
+  double       *all_block[PMG_IPC_MAXRANKS];
+  double      **ag_dst_dev[2];         /* device arrays [nranks]: peers' gather areas of each parity */
+  uint64_t    **ag_flag_dev;           /* device array [nranks]: peers' flag word 8 + my rank */
+  uint64_t      aground;
+  int           all_connected;
   pmg_grid      g;
   int           rank, nranks, lo, hi; /* z-neighbours (-1 = physical boundary); lo == hi == rank in loopback mode */
   int           loopback;
@@ -190,7 +197,7 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
   d->nz               = L.nz;
   d->plane            = L.sp;
   d->gcap             = 2 * d->plane > ((int64_t)1 << 19) ? 2 * d->plane : ((int64_t)1 << 19); /* two colour planes of the fine level, or 4 MB */
-  const size_t bytes  = sizeof(double) * (size_t)(PMG_IPC_HDR + 4 * d->plane + 4 * d->gcap);
+  const size_t bytes  = sizeof(double) * (size_t)(PMG_IPC_HDR + 4 * d->plane + 6 * d->gcap); /* flags, colour planes, 4 generic slots, 2 gather areas */
   /* fine-grained device memory: flag words and planes are written by a PEER device while this device's kernels poll
      and read them IN THE SAME KERNEL, so the block must be coherent at system scope without cache maintenance (what
      RCCL uses for its peer-written buffers) */
@@ -251,6 +258,39 @@ pmg_status pmg_dist_ipc_connect(pmg_dist d, const void *blob_lo, const void *blo
     d->peer_recv[side]  = d->peer_block[side] + PMG_IPC_HDR;
     d->peer_grecv[side] = d->peer_recv[side] + 4 * d->plane;
   }
+  return PMG_SUCCESS;
+}
+
+/* optional: map EVERY rank's block (blobs[r], r = 0..nranks-1; own entry ignored) so that pmg_dist_allgather is one
+   push + one wait instead of nranks - 1 rounds along the chain.  Call after pmg_dist_ipc_connect. */
+pmg_status pmg_dist_ipc_connect_all(pmg_dist d, const void *const *blobs)
+{
+  PMG_CHECK(d && d->transport == 1 && blobs, PMG_ERR_ARG_WRONG, "not an IPC dist object");
+  if (d->nranks == 1 || d->loopback) return PMG_SUCCESS;
+  double   *dst[2][PMG_IPC_MAXRANKS];
+  uint64_t *flg[PMG_IPC_MAXRANKS];
+  for (int r = 0; r < d->nranks; ++r) {
+    dst[0][r] = dst[1][r] = NULL;
+    flg[r]                = NULL;
+    if (r == d->rank) continue;
+    if (r == d->lo) d->all_block[r] = d->peer_block[0];
+    else if (r == d->hi) d->all_block[r] = d->peer_block[1];
+    else {
+      PMG_CHECK(blobs[r], PMG_ERR_ARG_NULL, "missing blob of rank %d", r);
+      pmg_ipc_blob bl;
+      memcpy(&bl, blobs[r], sizeof bl);
+      PMG_CHECK(bl.plane == d->plane && bl.gcap == d->gcap, PMG_ERR_ARG_SIZ, "rank %d has a different receive block", r);
+      PMG_HIP(hipIpcOpenMemHandle((void **)&d->all_block[r], bl.mem, hipIpcMemLazyEnablePeerAccess));
+    }
+    double *gather = d->all_block[r] + PMG_IPC_HDR + 4 * d->plane + 4 * d->gcap;
+    dst[0][r]      = gather;
+    dst[1][r]      = gather + d->gcap;
+    flg[r]         = (uint64_t *)d->all_block[r] + 8 + d->rank;
+  }
+  PMG_CHECK(8 + d->nranks <= PMG_IPC_HDR, PMG_ERR_ARG_OUTOFRANGE, "too many ranks for the flag header");
+  for (int q = 0; q < 2; ++q) PMG_CALL(pmg_dev_upload((void **)&d->ag_dst_dev[q], dst[q], sizeof(double *) * (size_t)d->nranks));
+  PMG_CALL(pmg_dev_upload((void **)&d->ag_flag_dev, flg, sizeof(uint64_t *) * (size_t)d->nranks));
+  d->all_connected = 1;
   return PMG_SUCCESS;
 }
 
@@ -378,6 +418,11 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
       if (d->peer_block[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
     for (int q = 0; q < PMG_IPC_WINDOW; ++q)
       if (d->evT[q]) (void)hipEventDestroy(d->evT[q]);
+    for (int r = 0; r < d->nranks && d->all_connected; ++r)
+      if (d->all_block[r] && r != d->lo && r != d->hi && r != d->rank) (void)hipIpcCloseMemHandle(d->all_block[r]);
+    pmg_dev_free(d->ag_dst_dev[0]);
+    pmg_dev_free(d->ag_dst_dev[1]);
+    pmg_dev_free(d->ag_flag_dev);
     if (d->err_dev) (void)hipHostFree(d->err_dev);
     pmg_dev_free(d->xch_counter);
     if (d->block) (void)hipFree(d->block);
@@ -468,8 +513,9 @@ pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo,
 }
 
 /* every rank ends up with all blocks: block r = counts[r] doubles at buf + offsets[r], rank r owns block r.
-   RCCL: one group of sends to / receives from every other rank.  IPC (neighbour links only): nranks - 1 rounds of
-   passing blocks along the chain in both directions. */
+   RCCL: one group of sends to / receives from every other rank.  IPC: with all-peer mappings
+   (pmg_dist_ipc_connect_all) one push of my block into every rank's gather area + one wait + one local copy;
+   with neighbour links only, nranks - 1 rounds of passing blocks along the chain in both directions. */
 pmg_status pmg_dist_allgather(pmg_dist d, double *buf, const int64_t *offsets, const int64_t *counts, void *stream)
 {
   PMG_CHECK(d && buf && offsets && counts, PMG_ERR_ARG_NULL, "null argument");
@@ -488,6 +534,37 @@ pmg_status pmg_dist_allgather(pmg_dist d, double *buf, const int64_t *offsets, c
     PMG_HIP(hipEventRecord(d->evGx, d->cs));
     PMG_HIP(hipStreamWaitEvent(s, d->evGx, 0));
     return PMG_SUCCESS;
+  }
+  if (d->all_connected) { /* one push into every rank's gather area, one wait, one local copy out */
+    int64_t base = offsets[0], end = offsets[0] + counts[0];
+    int     tiled = 1;
+    for (int r = 1; r < d->nranks; ++r) {
+      if (offsets[r] != end) tiled = 0; /* the blocks must tile one contiguous range in rank order (plane ranges do) */
+      end = offsets[r] + counts[r];
+    }
+    if (tiled && end - base <= d->gcap) {
+      PMG_CALL(ipc_check(d));
+      const int p = (int)(d->aground & 1);
+      d->aground += 1;
+      const double *mine = d->block + PMG_IPC_HDR + 4 * d->plane + 4 * d->gcap + (int64_t)p * d->gcap; /* my gather area */
+      PMG_KERNEL(pmgk_allgather_push(d->nranks, d->rank, buf + offsets[d->rank], counts[d->rank], d->ag_dst_dev[p], offsets[d->rank] - base, d->ag_flag_dev, d->aground, d->xch_counter, s));
+      PMG_KERNEL(pmgk_allgather_wait(d->nranks, d->rank, (const uint64_t *)d->block + 8, d->aground, d->err_dev, s));
+      pmgk_xch_args pull;
+      memset(&pull, 0, sizeof pull);
+      const int64_t lo_n = offsets[d->rank] - base, hi_0 = offsets[d->rank] + counts[d->rank];
+      if (lo_n > 0) {
+        pull.src[pull.nseg] = mine;
+        pull.dst[pull.nseg] = buf + base;
+        pull.n[pull.nseg++] = lo_n;
+      }
+      if (end - hi_0 > 0) {
+        pull.src[pull.nseg] = mine + (hi_0 - base);
+        pull.dst[pull.nseg] = buf + hi_0;
+        pull.n[pull.nseg++] = end - hi_0;
+      }
+      PMG_KERNEL(pmgk_xch_pull(&pull, d->err_dev, s));
+      return ipc_throttle(d, s);
+    }
   }
   for (int t = 1; t < d->nranks; ++t) {
     /* upward: I pass block (rank - t + 1) to hi and receive block (rank - t) from lo; downward mirrored */

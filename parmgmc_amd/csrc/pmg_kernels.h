@@ -148,6 +148,11 @@ typedef struct {
   uint64_t      value[4];
 } pmgk_xch_args;
 int pmgk_xch_push(const pmgk_xch_args *a, unsigned *counter, void *stream);
+/* all-gather over all-peer mappings: push = copy my block (n doubles at src) to dst[p] + dst_off for every peer
+   p != me (device array of nranks pointers; null = skip), then raise flag[p] (device array) to value from the last
+   block; wait = until myflags[p] >= value for every p != me */
+int pmgk_allgather_push(int nranks, int me, const double *src, int64_t n, double *const *dst_dev, int64_t dst_off, uint64_t *const *flag_dev, uint64_t value, unsigned *counter, void *stream);
+int pmgk_allgather_wait(int nranks, int me, const uint64_t *myflags, uint64_t value, unsigned *err, void *stream);
 int pmgk_xch_pull(const pmgk_xch_args *a, unsigned *err, void *stream);
 int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream);
 

@@ -187,6 +187,10 @@ class IpcSlabDriver(RcclSlabDriver):
         lo = C.create_string_buffer(blobs[rank - 1], nb.value) if rank > 0 else None
         hi = C.create_string_buffer(blobs[rank + 1], nb.value) if rank < world - 1 else None
         check(lib.pmg_dist_ipc_connect(self._h, lo, hi))
+        if world > 2:  # all-peer mappings: the all-gather of the distributed V-cycle becomes one step
+            bufs = [C.create_string_buffer(b_, nb.value) for b_ in blobs]
+            arr = (C.c_void_p * world)(*[C.cast(b_, C.c_void_p) for b_ in bufs])
+            check(lib.pmg_dist_ipc_connect_all(self._h, arr))
         dist.barrier(group=group)
         self._selftest(rank, world)
 
@@ -213,6 +217,17 @@ class IpcSlabDriver(RcclSlabDriver):
             raise RuntimeError("ipc halo self-test: wrong data from the low neighbour")
         if rank < world - 1 and not torch.equal(recv[1], float(rank + 2) + frac):
             raise RuntimeError("ipc halo self-test: wrong data from the high neighbour")
+        # all-gather (all-peer mappings for more than two ranks): rank r contributes 64 + r values
+        counts = [64 + r for r in range(world)]
+        offs = [sum(counts[:r]) for r in range(world)]
+        buf = torch.zeros(sum(counts), dtype=torch.float64, device="cuda")
+        buf[offs[rank]:offs[rank] + counts[rank]] = float(rank + 1)
+        A64 = C.c_int64 * world
+        check(lib.pmg_dist_allgather(self._h, _ptr(buf), A64(*offs), A64(*counts), _stream()))
+        torch.cuda.synchronize()
+        want = torch.cat([torch.full((counts[r],), float(r + 1), dtype=torch.float64, device="cuda") for r in range(world)])
+        if not torch.equal(buf, want):
+            raise RuntimeError("ipc halo self-test: all-gather returned wrong data")
 
 
 class DistGridSampler:
