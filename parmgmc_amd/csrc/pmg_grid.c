@@ -196,6 +196,16 @@ static pmg_status grid_det_sweep(void *ctx, int dir, const double *b, double *y,
   return PMG_SUCCESS;
 }
 
+/* the same from B already in cvec layout on the device (cvec_len x k); used by the multigrid set-up, which restricts
+   the observation vectors level by level on the device */
+pmg_status pmg_grid_set_lowrank_dev(pmg_grid g, int32_t k, const double *B_cvec_dev, const double *S_host)
+{
+  PMG_CHECK(g && B_cvec_dev && S_host, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(g->L.nz == g->L.nzg, PMG_ERR_SUP, "low-rank updates are single-device");
+  pmg_lrc_destroy(&g->lrc);
+  return pmg_lrc_build_dev(&g->lrc, k, 2 * g->L.cs, B_cvec_dev, S_host, grid_det_sweep, g, NULL, NULL);
+}
+
 /* MCSORSetUp's MATLRC branch (src/mc_sor.c:572-595) for the grid operator: B is (nx*ny*nz) x k column-major in
    DMDA natural order, S the k diagonal entries of Sigma^-1.  Uses the CURRENT omega.  k = 0 removes the update.
    Single-device grids only (the dense B^T y reduction over devices is not built). */

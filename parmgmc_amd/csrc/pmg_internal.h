@@ -38,6 +38,7 @@ pmg_status pmg_set_error(pmg_status code, const char *file, int line, const char
 
 static inline int pmg_sweep_type_ok(int t) { return t == PMG_SOR_FORWARD_SWEEP || t == PMG_SOR_BACKWARD_SWEEP || t == PMG_SOR_SYMMETRIC_SWEEP; }
 
+pmg_status pmg_grid_set_lowrank_dev(pmg_grid g, int32_t k, const double *B_cvec_dev, const double *S_host);
 pmg_status pmg_grid_sweep_color_halo_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const pmgk_grid_halo *halo, const double *b, double *y, void *stream);
 pmg_status pmg_grid_sweep_color_faces_cvec(pmg_grid g, int color, int noisy, int scaled, uint64_t seed, uint64_t counter, const pmgk_grid_halo *halo, const double *b, double *y, void *stream);
 /* kernel-side description of a grid object (internal) */
@@ -47,6 +48,8 @@ pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L);
 /* low-rank (MATLRC) helper shared by pmg_mcsor and pmg_grid (pmg_lrc.c); vectors in the sampler's layout */
 typedef struct pmg_lrc_s *pmg_lrc;
 typedef pmg_status (*pmg_det_sweep_fn)(void *ctx, int dir, const double *b_lay, double *y_lay, void *stream);
+typedef pmg_status (*pmg_lrc_reduce_fn)(void *ctx, double *vals_dev, int count, void *stream);
+pmg_status pmg_lrc_build_dev(pmg_lrc *out, int32_t k, int64_t ld, const double *B_lay_dev, const double *S_host, pmg_det_sweep_fn det, void *ctx, pmg_lrc_reduce_fn reduce, void *rctx);
 pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const double *B_nat_host, const int64_t *pos, const double *S_host, pmg_det_sweep_fn det, void *ctx);
 pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t counter, const double **beff, void *stream);
 pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream); /* after the sweep that used the vector pmg_lrc_rhs returned */

@@ -28,6 +28,8 @@ struct pmg_lrc_s {
   double  *Bc, *Bbc[2];      /* device, ns x k column-major */
   double  *saved;            /* device, ns: the right-hand side entries under the noise term */
   double  *b_mod;            /* the vector whose support rows currently carry the noise term */
+  pmg_lrc_reduce_fn reduce;  /* row-distributed operator: sum of the k-vectors over the ranks */
+  void             *rctx;
 };
 
 void pmg_lrc_destroy(pmg_lrc *p)
@@ -133,32 +135,29 @@ static pmg_status lrc_compact(pmg_lrc l)
   return PMG_SUCCESS;
 }
 
-pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const double *B_nat_host, const int64_t *pos, const double *S_host, pmg_det_sweep_fn det, void *ctx)
+/* the correction from B already in the sampler's layout on the device (ld x k, zero outside the rows it touches);
+   B_lay_dev is copied.  reduce != NULL: the k-vectors B^T y are partial sums of a row-distributed operator and
+   reduce(rctx, wk_dev, count, stream) must turn `count` device doubles into their sum over all ranks (same result on
+   every rank) -- the hook of the distributed samplers. */
+pmg_status pmg_lrc_build_dev(pmg_lrc *out, int32_t k, int64_t ld, const double *B_lay_dev, const double *S_host, pmg_det_sweep_fn det, void *ctx, pmg_lrc_reduce_fn reduce, void *rctx)
 {
-  PMG_CHECK(out && B_nat_host && pos && S_host && det, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(out && B_lay_dev && S_host && det, PMG_ERR_ARG_NULL, "null argument");
   PMG_CHECK(k >= 1 && k <= 64, PMG_ERR_ARG_OUTOFRANGE, "rank k = %d (1..64 supported)", k);
   *out      = NULL;
   pmg_lrc l = (pmg_lrc)calloc(1, sizeof *l);
   PMG_CHECK(l, PMG_ERR_MEM, "out of host memory");
-  l->k  = k;
-  l->ld = ld;
-  /* B in layout order */
-  double *Bl = (double *)calloc((size_t)ld * k, sizeof(double));
-  double *sq = (double *)malloc(sizeof(double) * (size_t)k);
-  if (!Bl || !sq) {
-    free(Bl); free(sq); free(l);
-    PMG_FAIL(PMG_ERR_MEM, "out of host memory");
-  }
-  for (int c = 0; c < k; ++c)
-    for (int32_t r = 0; r < n; ++r) Bl[pos[r] + ld * c] = B_nat_host[r + (size_t)n * c];
+  l->k      = k;
+  l->ld     = ld;
+  l->reduce = reduce;
+  l->rctx   = rctx;
+  double sq[64];
   for (int c = 0; c < k; ++c) sq[c] = sqrt(fabs(S_host[c])); /* VecSqrtAbs(sqrtS), src/pc_mcgibbs.c:240-242 */
-  pmg_status st = pmg_dev_upload((void **)&l->B, Bl, sizeof(double) * (size_t)ld * k);
-  free(Bl);
+  pmg_status st = pmg_dev_alloc((void **)&l->B, sizeof(double) * (size_t)ld * k);
+  if (!st && hipMemcpy(l->B, B_lay_dev, sizeof(double) * (size_t)ld * k, hipMemcpyDeviceToDevice) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "copy failed");
   if (!st) st = pmg_dev_upload((void **)&l->S, S_host, sizeof(double) * (size_t)k);
   if (!st) st = pmg_dev_upload((void **)&l->sqrtS, sq, sizeof(double) * (size_t)k);
-  free(sq);
   for (int d = 0; d < 2 && !st; ++d) st = pmg_dev_alloc((void **)&l->Bb[d], sizeof(double) * (size_t)ld * k);
-  if (!st) st = pmg_dev_alloc((void **)&l->wk, sizeof(double) * 64);
+  if (!st) st = pmg_dev_alloc((void **)&l->wk, sizeof(double) * 64 * 64); /* k values per sweep; k*k while T is formed */
   if (!st) st = pmg_dev_alloc((void **)&l->eta, sizeof(double) * 64);
   if (!st) st = pmg_dev_alloc((void **)&l->partial, sizeof(double) * (size_t)pmgk_lrc_nblocks(ld) * k);
   if (!st) st = pmg_dev_alloc((void **)&l->beff, sizeof(double) * (size_t)ld);
@@ -172,10 +171,10 @@ pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const d
       if (hipMemsetAsync(l->col + ld * c, 0, sizeof(double) * (size_t)ld, NULL) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
       if (!st) st = det(ctx, dir, l->B + ld * c, l->col + ld * c, NULL);
     }
-    for (int c = 0; c < k && !st; ++c) { /* T(:,c) = B^T C(:,c), src/mc_sor.c:514 */
-      if (pmgk_lrc_btx(ld, k, l->B, ld, l->col + ld * c, l->partial, NULL, l->wk, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
-      if (!st && hipMemcpy(T + (size_t)k * c, l->wk, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
-    }
+    for (int c = 0; c < k && !st; ++c) /* T(:,c) = B^T C(:,c), src/mc_sor.c:514 */
+      if (pmgk_lrc_btx(ld, k, l->B, ld, l->col + ld * c, l->partial, NULL, l->wk + (size_t)k * c, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
+    if (!st && l->reduce) st = l->reduce(l->rctx, l->wk, k * k, NULL);
+    if (!st && hipMemcpy(T, l->wk, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
     if (st) break;
     for (int c = 0; c < k; ++c) T[c + (size_t)k * c] += 1.0 / S_host[c]; /* + S^-1, src/mc_sor.c:525-527 */
     if (pmg_invert_small(k, T, Sb)) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "S^-1 + B^T M^-1 B is singular");
@@ -193,6 +192,22 @@ pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const d
   }
   *out = l;
   return PMG_SUCCESS;
+}
+
+/* the same from a host matrix in natural numbering: pos[r] = layout position of natural row r */
+pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const double *B_nat_host, const int64_t *pos, const double *S_host, pmg_det_sweep_fn det, void *ctx)
+{
+  PMG_CHECK(out && B_nat_host && pos && S_host && det, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(k >= 1 && k <= 64, PMG_ERR_ARG_OUTOFRANGE, "rank k = %d (1..64 supported)", k);
+  double *Bl = (double *)calloc((size_t)ld * k, sizeof(double)), *Bd = NULL;
+  PMG_CHECK(Bl, PMG_ERR_MEM, "out of host memory");
+  for (int c = 0; c < k; ++c)
+    for (int32_t r = 0; r < n; ++r) Bl[pos[r] + ld * c] = B_nat_host[r + (size_t)n * c];
+  pmg_status st = pmg_dev_upload((void **)&Bd, Bl, sizeof(double) * (size_t)ld * k);
+  free(Bl);
+  if (!st) st = pmg_lrc_build_dev(out, k, ld, Bd, S_host, det, ctx, NULL, NULL);
+  pmg_dev_free(Bd);
+  return st;
 }
 
 /* b_eff = b + B (sqrt(S) o eta), eta = row-stream normals of (seed + tag, counter); returns the device vector to
@@ -230,10 +245,12 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
 {
   if (l->ns) {
     PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, x_lay, l->partial, l->S, l->wk, stream));
+    if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream)); /* S scales every partial sum alike */
     PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->wk, -1.0, r_lay, NULL, stream));
     return PMG_SUCCESS;
   }
   PMG_KERNEL(pmgk_lrc_btx(l->ld, l->k, l->B, l->ld, x_lay, l->partial, l->S, l->wk, stream));
+  if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream));
   PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->B, l->ld, l->wk, -1.0, r_lay, r_lay, stream));
   return PMG_SUCCESS;
 }
@@ -244,10 +261,12 @@ pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
   const int d = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
   if (l->ns) {
     PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, y_lay, l->partial, NULL, l->wk, stream));
+    if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream));
     PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, NULL, stream));
     return PMG_SUCCESS;
   }
   PMG_KERNEL(pmgk_lrc_btx(l->ld, l->k, l->B, l->ld, y_lay, l->partial, NULL, l->wk, stream));
+  if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream));
   PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->Bb[d], l->ld, l->wk, -1.0, y_lay, y_lay, stream));
   return PMG_SUCCESS;
 }

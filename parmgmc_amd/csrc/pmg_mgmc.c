@@ -634,7 +634,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
   if (h->user_hier) return mgmc_setup_user(h);
   const int top = h->nlevels - 1;
   if (h->dist) PMG_CHECK(!h->keep_host && !h->lrc_k, PMG_ERR_SUP, "host copies and low-rank updates are single-device features");
-  if (h->dist || (!h->keep_host && !h->lrc_k && !getenv("PMG_MG_FULL_GALERKIN") && !getenv("PMG_MG_NO_STENCIL") && !getenv("PMG_MG_CSR_TRANSFERS"))) {
+  if (h->dist || (!h->keep_host && !getenv("PMG_MG_FULL_GALERKIN") && !getenv("PMG_MG_NO_STENCIL") && !getenv("PMG_MG_CSR_TRANSFERS"))) {
     /* class-stencil tables from the proxy hierarchy: no product with the full-size matrices */
     st27_table *tab = (st27_table *)malloc(sizeof(st27_table) * (size_t)top);
     PMG_CHECK(tab, PMG_ERR_MEM, "out of host memory");
@@ -986,6 +986,60 @@ static pmg_status st27_to_csr(int nx, int ny, int nz, const st27_table *t, hcsr 
   return PMG_SUCCESS;
 }
 
+/* MATLRC operators of a class-stencil hierarchy (PCGAMGMC_SetUpHierarchy, src/pc_gamgmc.c:157-196): the factor B of the
+   finest level is restricted level by level ON THE DEVICE, column by column, with the restriction kernels of the
+   V-cycle (B_{l-1} = P_l^T B_l, :177), every level sampler gets A_l + B_l S B_l^T; the coarsest block is returned in
+   natural numbering for the dense factorisation (src/pc_chols.c:119-153). */
+static pmg_status stencil_attach_lowrank(pmg_mgmc h, double **B0_host)
+{
+  const int     top = h->nlevels - 1, k = h->lrc_k;
+  mg_level     *F   = &h->lv[top];
+  double       *Bcur = NULL, *tmp = NULL;
+  *B0_host           = NULL;
+  PMG_CALL(pmg_dev_alloc((void **)&Bcur, sizeof(double) * (size_t)F->ld * k));
+  PMG_HIP(hipMemset(Bcur, 0, sizeof(double) * (size_t)F->ld * k));
+  PMG_CALL(pmg_dev_alloc((void **)&tmp, sizeof(double) * (size_t)F->n));
+  for (int c = 0; c < k; ++c) { /* natural host column -> cvec */
+    PMG_HIP(hipMemcpy(tmp, h->lrc_B + (size_t)F->n * c, sizeof(double) * (size_t)F->n, hipMemcpyHostToDevice));
+    PMG_CALL(pmg_grid_to_cvec(F->g, tmp, Bcur + (size_t)F->ld * c, NULL));
+  }
+  PMG_HIP(hipDeviceSynchronize());
+  pmg_dev_free(tmp);
+  PMG_CALL(pmg_grid_set_lowrank_dev(F->g, k, Bcur, h->lrc_S));
+  for (int l = top; l >= 1; --l) {
+    mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
+    double   *Bnext = NULL;
+    PMG_CALL(pmg_dev_alloc((void **)&Bnext, sizeof(double) * (size_t)Cc->ld * k));
+    PMG_HIP(hipMemset(Bnext, 0, sizeof(double) * (size_t)Cc->ld * k));
+    const pmgk_st27_dims CD = level_dims(Cc);
+    for (int c = 0; c < k; ++c) {
+      if (Lv->is_grid) {
+        pmgk_grid_layout GL;
+        PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
+        PMG_KERNEL(pmgk_q1_restrict(&GL, &CD, NULL, Bcur + (size_t)Lv->ld * c, Bnext + (size_t)Cc->ld * c, NULL));
+      } else {
+        const pmgk_st27_dims FD = level_dims(Lv);
+        PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, Bcur + (size_t)Lv->ld * c, Bnext + (size_t)Cc->ld * c, NULL));
+      }
+    }
+    PMG_HIP(hipDeviceSynchronize());
+    pmg_dev_free(Bcur);
+    Bcur = Bnext;
+    if (Cc->is_st27) { /* a sampled level (not the Cholesky level) */
+      st27_det_ctx ctx = {h, Cc};
+      PMG_CALL(pmg_lrc_build_dev(&Cc->lrc, k, Cc->ld, Bcur, h->lrc_S, st27_det_sweep, &ctx, NULL, NULL));
+    }
+  }
+  /* coarsest block to the host, natural numbering (the padded layout minus its ghost planes) */
+  mg_level *C0 = &h->lv[0];
+  double   *B0 = (double *)malloc(sizeof(double) * (size_t)C0->n * k);
+  PMG_CHECK(B0, PMG_ERR_MEM, "out of host memory");
+  for (int c = 0; c < k; ++c) PMG_HIP(hipMemcpy(B0 + (size_t)C0->n * c, Bcur + (size_t)C0->ld * c + C0->off, sizeof(double) * (size_t)C0->n, hipMemcpyDeviceToHost));
+  pmg_dev_free(Bcur);
+  *B0_host = B0;
+  return PMG_SUCCESS;
+}
+
 /* set-up from class-stencil tables: every level below the grid level is a class-stencil level in padded natural
    order, transfers are the matrix-free Q1 kernels, the coarsest level is factored from the expanded table */
 static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
@@ -1029,14 +1083,19 @@ static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
     if (l > 0 || h->coarse_type == 1) PMG_CALL(st27_install(Lv, tab[l].coef, tab[l].have, h->omega));
     if (l > 0) Lv->nat_transfer = 1;
   }
+  double *B0_host = NULL; /* coarsest block of the low-rank factor, natural numbering, for the dense factorisation */
+  if (h->lrc_k) PMG_CALL(stencil_attach_lowrank(h, &B0_host));
   if (h->coarse_type == 0) {
     mg_level *C0 = &h->lv[0];
     hcsr      A0;
     PMG_CHECK(!C0->distributed, PMG_ERR_SUP, "the Cholesky level must not be distributed");
     PMG_CALL(st27_to_csr(C0->nx, C0->ny, C0->nz, &tab[0], &A0));
-    pmg_status st = pmg_chol_create_csr(C0->n, A0.rp, A0.ci, A0.v, &h->chol);
+    pmg_status st = pmg_chol_create_csr_lowrank(C0->n, A0.rp, A0.ci, A0.v, h->lrc_k, B0_host, h->lrc_S, &h->chol);
     hcsr_free(&A0);
+    free(B0_host);
     PMG_CALL(st);
+  } else {
+    free(B0_host);
   }
   for (int l = 0; l <= top; ++l) {
     mg_level *Lv = &h->lv[l];
