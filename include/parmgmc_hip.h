@@ -207,6 +207,10 @@ pmg_status pmg_dist_ipc_connect_loopback(pmg_dist d);
    chain is bit-identical for every number of ranks.  Work is enqueued on `stream` and an internal comm stream;
    `stream` is made to wait for the last exchange before the call returns. */
 pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b_cvec, double *y_cvec, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+/* MCSORApply on the slabs: one deterministic sweep (forward / backward / symmetric) with the same halo schedule */
+pmg_status pmg_dist_apply_cvec(pmg_dist d, const double *b_cvec, double *y_cvec, int sweep_type, void *stream);
+/* vals[0..count) (device, count <= 4096) <- sum over all ranks, formed in rank order on every rank */
+pmg_status pmg_dist_allreduce_sum(pmg_dist d, double *vals_dev, int32_t count, void *stream);
 /* Building blocks of the distributed V-cycle on the same transports.  pmg_dist_exchange: one round trip with both
    z-neighbours on `stream`, nseg (<= 4) contiguous device segments per side; what is sent to the low neighbour
    arrives in its high receive segments and vice versa (segment sizes of a pair must agree; sides without a neighbour

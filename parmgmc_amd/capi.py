@@ -140,6 +140,8 @@ _sig = {
     "pmg_dist_exchange": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmg_dist_allgather": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "pmg_dist_ipc_connect_all": (_int, [_vp, _vp]),
+    "pmg_dist_apply_cvec": (_int, [_vp, _vp, _vp, _int, _vp]),
+    "pmg_dist_allreduce_sum": (_int, [_vp, _vp, _i32, _vp]),
     "pmg_dist_check": (_int, [_vp]),
     "pmg_dist_get_info": (_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_int64)]),
     "pmg_mgmc_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),

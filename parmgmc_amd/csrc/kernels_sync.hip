@@ -106,9 +106,25 @@ __global__ void allgather_wait_kernel(int nranks, int me, const uint64_t *myflag
   }
 }
 
+__global__ void sum_rows_kernel(int nrows, int count, const double *__restrict__ in, double *__restrict__ out)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= count) return;
+  double s = 0.0;
+  for (int r = 0; r < nrows; ++r) s = s + in[(int64_t)r * count + c];
+  out[c] = s;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
+
+extern "C" int pmgk_sum_rows(int nrows, int count, const double *in, double *out, void *stream)
+{
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, nrows, count, in, out);
+  return launch_status();
+}
 
 extern "C" int pmgk_allgather_push(int nranks, int me, const double *src, int64_t n, double *const *dst_dev, int64_t dst_off, uint64_t *const *flag_dev, uint64_t value, unsigned *counter, void *stream)
 {

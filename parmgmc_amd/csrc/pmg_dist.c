@@ -100,6 +100,7 @@ struct pmg_dist_s {
   uint64_t      nthrottle;
   unsigned     *err_dev;               /* pinned host word (device-visible), set by a flag wait that gave up */
   unsigned     *xch_counter;           /* device: blocks of the push kernel that have finished */
+  double       *red_buf;               /* device: nranks x 4096 partial sums of pmg_dist_allreduce_sum */
   /* all-peer mappings (optional, pmg_dist_ipc_connect_all): single-step all-gather.  Every block has, behind the
      generic slots, two gather areas (parity) of gcap doubles; flag word 8 + src announces rank src's block */
   double       *all_block[PMG_IPC_MAXRANKS];
@@ -339,7 +340,7 @@ static pmg_status ipc_check(pmg_dist d)
    neighbours' planes a colour needs were pushed one whole colour pass earlier, so nothing waits in steady state; no
    second stream, no events, no host rendezvous.  Safe re-use of a receive slot: my faces of colour c overwrite the
    neighbour's slot c only after its push of colour 1-c has arrived, which it issued after reading slot c. */
-static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, hipStream_t s)
+static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, hipStream_t s)
 {
   int64_t own, ghost, n;
   PMG_CALL(ipc_check(d));
@@ -383,7 +384,7 @@ static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its
         h.sval    = d->round[c];
         h.counter = d->xch_counter + 1;
         h.err     = d->err_dev;
-        PMG_CALL(pmg_grid_sweep_color_halo_cvec(d->g, c, 1, scaled, seed, ctr, &h, b, y, s));
+        PMG_CALL(pmg_grid_sweep_color_halo_cvec(d->g, c, noisy, scaled, seed, ctr, &h, b, y, s));
       }
       if ((ctr & 1) == 1) PMG_CALL(ipc_throttle(d, s)); /* an event every other sweep: each one costs a marker on the stream */
       ++ctr;
@@ -427,6 +428,7 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
     pmg_dev_free(d->xch_counter);
     if (d->block) (void)hipFree(d->block);
   }
+  pmg_dev_free(d->red_buf);
   if (d->comm && d->api.CommDestroy) d->api.CommDestroy(d->comm);
   for (int c = 0; c < 2; ++c) {
     if (d->evB[c]) (void)hipEventDestroy(d->evB[c]);
@@ -621,15 +623,15 @@ static pmg_status dist_exchange(pmg_dist d, int c, double *y, hipEvent_t after)
   return PMG_SUCCESS;
 }
 
-/* The distributed sample loop: `its` samples of the sorgibbs/mcgibbs chain on this rank's slab (cvec vectors). */
-pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b, double *y, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+/* `its` sweeps on this rank's slab (cvec vectors), noisy (the sample loop) or deterministic (MCSORApply) */
+static pmg_status dist_sweeps(pmg_dist d, const double *b, double *y, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
 {
   PMG_CHECK(d && b && y, PMG_ERR_ARG_NULL, "null argument");
   PMG_CHECK(its >= 0, PMG_ERR_ARG_OUTOFRANGE, "its = %d", its);
   PMG_CHECK(pmg_sweep_type_ok(sweep_type), PMG_ERR_SUP, "Only forward, backward and symmetric sweep supported");
   hipStream_t   s  = (hipStream_t)stream;
   const int32_t nz = d->nz;
-  if (d->transport == 1) return ipc_sample(d, b, y, its, scaled, sweep_type, seed, counter0, counter_out, s);
+  if (d->transport == 1) return ipc_sample(d, b, y, its, noisy, scaled, sweep_type, seed, counter0, counter_out, s);
   /* the caller's y has no ghost values yet: exchange both colours once the caller's prior work is done */
   PMG_HIP(hipEventRecord(d->evS, s));
   PMG_CALL(dist_exchange(d, 0, y, d->evS));
@@ -642,10 +644,10 @@ pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b, double *y, int32_t 
       for (int cc = 0; cc < 2; ++cc) {
         const int c = dir == PMG_SOR_FORWARD_SWEEP ? cc : 1 - cc;
         PMG_HIP(hipStreamWaitEvent(s, d->evX[1 - c], 0)); /* colour c reads colour 1-c across the slab faces */
-        PMG_CALL(pmg_grid_sweep_color_faces_cvec(d->g, c, 1, scaled, seed, ctr, NULL, b, y, s)); /* planes 0 and nz-1, one launch */
+        PMG_CALL(pmg_grid_sweep_color_faces_cvec(d->g, c, noisy, scaled, seed, ctr, NULL, b, y, s)); /* planes 0 and nz-1, one launch */
         PMG_HIP(hipEventRecord(d->evB[c], s));
         PMG_CALL(dist_exchange(d, c, y, d->evB[c]));
-        if (nz > 2) PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, 1, nz - 2, 1, scaled, seed, ctr, b, y, s));
+        if (nz > 2) PMG_CALL(pmg_grid_sweep_color_planes_cvec(d->g, c, 1, nz - 2, noisy, scaled, seed, ctr, b, y, s));
       }
       ++ctr;
     }
@@ -653,5 +655,37 @@ pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b, double *y, int32_t 
   PMG_HIP(hipStreamWaitEvent(s, d->evX[0], 0));
   PMG_HIP(hipStreamWaitEvent(s, d->evX[1], 0));
   if (counter_out) *counter_out = ctr;
+  return PMG_SUCCESS;
+}
+
+/* The distributed sample loop: `its` samples of the sorgibbs/mcgibbs chain on this rank's slab (cvec vectors). */
+pmg_status pmg_dist_sample_cvec(pmg_dist d, const double *b, double *y, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+{
+  return dist_sweeps(d, b, y, its, 1, scaled, sweep_type, seed, counter0, counter_out, stream);
+}
+
+/* MCSORApply on the slabs: one deterministic sweep of the given type */
+pmg_status pmg_dist_apply_cvec(pmg_dist d, const double *b, double *y, int sweep_type, void *stream)
+{
+  return dist_sweeps(d, b, y, 1, 0, 0, sweep_type, 0, 0, NULL, stream);
+}
+
+/* vals[0..count) (device) <- their sum over all ranks, formed in rank order on every rank (identical bits
+   everywhere); count <= 4096.  One all-gather of the partial sums + a small kernel. */
+pmg_status pmg_dist_allreduce_sum(pmg_dist d, double *vals_dev, int32_t count, void *stream)
+{
+  PMG_CHECK(d && vals_dev, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(count >= 0 && count <= 4096, PMG_ERR_ARG_OUTOFRANGE, "count = %d", count);
+  if (d->nranks == 1 || count == 0) return PMG_SUCCESS;
+  if (!d->red_buf) PMG_CALL(pmg_dev_alloc((void **)&d->red_buf, sizeof(double) * 4096 * (size_t)d->nranks));
+  int64_t offs[PMG_IPC_MAXRANKS], cnts[PMG_IPC_MAXRANKS];
+  PMG_CHECK(d->nranks <= PMG_IPC_MAXRANKS, PMG_ERR_ARG_OUTOFRANGE, "too many ranks");
+  for (int r = 0; r < d->nranks; ++r) {
+    offs[r] = (int64_t)r * count;
+    cnts[r] = count;
+  }
+  PMG_HIP(hipMemcpyAsync(d->red_buf + offs[d->rank], vals_dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  PMG_CALL(pmg_dist_allgather(d, d->red_buf, offs, cnts, stream));
+  PMG_KERNEL(pmgk_sum_rows(d->nranks, count, d->red_buf, vals_dev, stream));
   return PMG_SUCCESS;
 }

@@ -28,6 +28,7 @@ struct pmg_lrc_s {
   double  *Bc, *Bbc[2];      /* device, ns x k column-major */
   double  *saved;            /* device, ns: the right-hand side entries under the noise term */
   double  *b_mod;            /* the vector whose support rows currently carry the noise term */
+  int      empty;            /* this rank's rows do not meet the support of B at all (row-distributed operator) */
   pmg_lrc_reduce_fn reduce;  /* row-distributed operator: sum of the k-vectors over the ranks */
   void             *rctx;
 };
@@ -103,6 +104,17 @@ static pmg_status lrc_compact(pmg_lrc l)
   pmg_dev_free(mask_dev);
   int64_t ns = 0;
   for (int64_t r = 0; r < l->ld && !st; ++r) ns += mask[r];
+  if (!st && ns == 0 && l->reduce) { /* nothing of B on this rank: only the (collective) reductions remain */
+    free(mask);
+    l->empty = 1;
+    pmg_dev_free(l->B);
+    pmg_dev_free(l->Bb[0]);
+    pmg_dev_free(l->Bb[1]);
+    pmg_dev_free(l->col);
+    pmg_dev_free(l->beff);
+    l->B = l->Bb[0] = l->Bb[1] = l->col = l->beff = NULL;
+    return PMG_SUCCESS;
+  }
   if (st || ns == 0 || ns > l->ld / 4) {
     free(mask);
     return st;
@@ -215,6 +227,10 @@ pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const d
    b itself is returned -- pmg_lrc_rhs_done puts the saved values back after the sweep, bit for bit. */
 pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t counter, const double **beff, void *stream)
 {
+  if (l->empty) {
+    *beff = b_lay;
+    return PMG_SUCCESS;
+  }
   PMG_KERNEL(pmgk_fill_normal_rows(l->k, seed + 0x632BE59BD9B4E019ull, counter, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w) */
   PMG_KERNEL(pmgk_lrc_mul(l->k, l->eta, l->sqrtS, l->eta, stream));                               /* VecPointwiseMult(w, w, sqrtS)   */
   if (l->ns) {
@@ -243,6 +259,10 @@ pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream)
    residual operator is pointed at for MATLRC levels, src/pc_gamgmc.c:186-194) */
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream)
 {
+  if (l->empty) { /* contribute zeros to the collective sum */
+    PMG_HIP(hipMemsetAsync(l->wk, 0, sizeof(double) * (size_t)l->k, (hipStream_t)stream));
+    return l->reduce(l->rctx, l->wk, l->k, stream);
+  }
   if (l->ns) {
     PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, x_lay, l->partial, l->S, l->wk, stream));
     if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream)); /* S scales every partial sum alike */
@@ -259,6 +279,10 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
 {
   const int d = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
+  if (l->empty) {
+    PMG_HIP(hipMemsetAsync(l->wk, 0, sizeof(double) * (size_t)l->k, (hipStream_t)stream));
+    return l->reduce(l->rctx, l->wk, l->k, stream);
+  }
   if (l->ns) {
     PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, y_lay, l->partial, NULL, l->wk, stream));
     if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream));

@@ -480,7 +480,7 @@ pmg_status pmg_mgmc_set_lowrank(pmg_mgmc h, int32_t k, const double *B_host, con
   h->lrc_k = 0;
   if (k == 0) return PMG_SUCCESS;
   PMG_CHECK(B_host && S_host, PMG_ERR_ARG_NULL, "null low-rank factor");
-  const int32_t n = h->lv[h->nlevels - 1].n;
+  const int32_t n = h->dist ? h->n_io : h->lv[h->nlevels - 1].n; /* z-slabs: the rows of this rank's planes */
   PMG_CHECK(n > 0, PMG_ERR_ARG_WRONGSTATE, "set the finest level operator before the low-rank update");
   h->lrc_B = (double *)malloc(sizeof(double) * (size_t)n * k);
   h->lrc_S = (double *)malloc(sizeof(double) * (size_t)k);
@@ -514,11 +514,31 @@ typedef struct {
   mg_level *Lv;
 } st27_det_ctx;
 
+static pmg_status halo_level(pmg_mgmc h, mg_level *Lv, double *v, void *stream);
+
 static pmg_status st27_det_sweep(void *ctx, int dir, const double *b, double *y, void *stream)
 {
   st27_det_ctx *c = (st27_det_ctx *)ctx;
-  PMG_KERNEL(pmgk_st27_sweep(&c->Lv->st, dir == PMG_SOR_BACKWARD_SWEEP, c->h->omega, 0, 0, 0, b, y, stream));
+  const int     backward = dir == PMG_SOR_BACKWARD_SWEEP;
+  if (c->Lv->distributed) { /* z-slab: the two z-parity phases with a halo of the boundary planes after each */
+    PMG_KERNEL(pmgk_st27_sweep_phase(&c->Lv->st, backward, 0, c->h->omega, 0, 0, 0, b, y, stream));
+    PMG_CALL(halo_level(c->h, c->Lv, y, stream));
+    PMG_KERNEL(pmgk_st27_sweep_phase(&c->Lv->st, backward, 1, c->h->omega, 0, 0, 0, b, y, stream));
+    PMG_CALL(halo_level(c->h, c->Lv, y, stream));
+    return PMG_SUCCESS;
+  }
+  PMG_KERNEL(pmgk_st27_sweep(&c->Lv->st, backward, c->h->omega, 0, 0, 0, b, y, stream));
   return PMG_SUCCESS;
+}
+
+/* deterministic sweep of the fine level of a z-slab hierarchy; sum of k-vectors over the ranks */
+static pmg_status dist_det_sweep(void *ctx, int dir, const double *b, double *y, void *stream)
+{
+  return pmg_dist_apply_cvec(((pmg_mgmc)ctx)->dist, b, y, dir, stream);
+}
+static pmg_status mg_reduce(void *ctx, double *vals_dev, int count, void *stream)
+{
+  return pmg_dist_allreduce_sum(((pmg_mgmc)ctx)->dist, vals_dev, count, stream);
 }
 
 /* MatCreateLRC(Ac, Bc, Sf) + KSPSetOperators on the level sampler (src/pc_gamgmc.c:178, :185-187): B_nat is the
@@ -633,7 +653,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
   if (h->is_setup) return PMG_SUCCESS;
   if (h->user_hier) return mgmc_setup_user(h);
   const int top = h->nlevels - 1;
-  if (h->dist) PMG_CHECK(!h->keep_host && !h->lrc_k, PMG_ERR_SUP, "host copies and low-rank updates are single-device features");
+  if (h->dist) PMG_CHECK(!h->keep_host, PMG_ERR_SUP, "host copies of the level matrices are a single-device feature");
   if (h->dist || (!h->keep_host && !getenv("PMG_MG_FULL_GALERKIN") && !getenv("PMG_MG_NO_STENCIL") && !getenv("PMG_MG_CSR_TRANSFERS"))) {
     /* class-stencil tables from the proxy hierarchy: no product with the full-size matrices */
     st27_table *tab = (st27_table *)malloc(sizeof(st27_table) * (size_t)top);
@@ -990,44 +1010,38 @@ static pmg_status st27_to_csr(int nx, int ny, int nz, const st27_table *t, hcsr 
    finest level is restricted level by level ON THE DEVICE, column by column, with the restriction kernels of the
    V-cycle (B_{l-1} = P_l^T B_l, :177), every level sampler gets A_l + B_l S B_l^T; the coarsest block is returned in
    natural numbering for the dense factorisation (src/pc_chols.c:119-153). */
+static pmg_status mg_restrict(pmg_mgmc h, int l, double *r_fine, double *b_coarse, void *stream);
+
 static pmg_status stencil_attach_lowrank(pmg_mgmc h, double **B0_host)
 {
-  const int     top = h->nlevels - 1, k = h->lrc_k;
-  mg_level     *F   = &h->lv[top];
-  double       *Bcur = NULL, *tmp = NULL;
-  *B0_host           = NULL;
+  const int  top = h->nlevels - 1, k = h->lrc_k;
+  mg_level  *F   = &h->lv[top];
+  double    *Bcur = NULL, *tmp = NULL;
+  const int32_t nrows = h->dist ? h->n_io : F->n;
+  *B0_host            = NULL;
   PMG_CALL(pmg_dev_alloc((void **)&Bcur, sizeof(double) * (size_t)F->ld * k));
   PMG_HIP(hipMemset(Bcur, 0, sizeof(double) * (size_t)F->ld * k));
-  PMG_CALL(pmg_dev_alloc((void **)&tmp, sizeof(double) * (size_t)F->n));
-  for (int c = 0; c < k; ++c) { /* natural host column -> cvec */
-    PMG_HIP(hipMemcpy(tmp, h->lrc_B + (size_t)F->n * c, sizeof(double) * (size_t)F->n, hipMemcpyHostToDevice));
+  PMG_CALL(pmg_dev_alloc((void **)&tmp, sizeof(double) * (size_t)nrows));
+  for (int c = 0; c < k; ++c) { /* natural host column (this rank's planes) -> cvec */
+    PMG_HIP(hipMemcpy(tmp, h->lrc_B + (size_t)nrows * c, sizeof(double) * (size_t)nrows, hipMemcpyHostToDevice));
     PMG_CALL(pmg_grid_to_cvec(F->g, tmp, Bcur + (size_t)F->ld * c, NULL));
   }
   PMG_HIP(hipDeviceSynchronize());
   pmg_dev_free(tmp);
-  PMG_CALL(pmg_grid_set_lowrank_dev(F->g, k, Bcur, h->lrc_S));
+  if (h->dist) PMG_CALL(pmg_lrc_build_dev(&F->lrc, k, F->ld, Bcur, h->lrc_S, dist_det_sweep, h, F->distributed ? mg_reduce : NULL, h)); /* the slab sweeps run in pmg_dist: the update is applied around them here */
+  else PMG_CALL(pmg_grid_set_lowrank_dev(F->g, k, Bcur, h->lrc_S));
   for (int l = top; l >= 1; --l) {
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
     double   *Bnext = NULL;
     PMG_CALL(pmg_dev_alloc((void **)&Bnext, sizeof(double) * (size_t)Cc->ld * k));
     PMG_HIP(hipMemset(Bnext, 0, sizeof(double) * (size_t)Cc->ld * k));
-    const pmgk_st27_dims CD = level_dims(Cc);
-    for (int c = 0; c < k; ++c) {
-      if (Lv->is_grid) {
-        pmgk_grid_layout GL;
-        PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
-        PMG_KERNEL(pmgk_q1_restrict(&GL, &CD, NULL, Bcur + (size_t)Lv->ld * c, Bnext + (size_t)Cc->ld * c, NULL));
-      } else {
-        const pmgk_st27_dims FD = level_dims(Lv);
-        PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, Bcur + (size_t)Lv->ld * c, Bnext + (size_t)Cc->ld * c, NULL));
-      }
-    }
+    for (int c = 0; c < k; ++c) PMG_CALL(mg_restrict(h, l, Bcur + (size_t)Lv->ld * c, Bnext + (size_t)Cc->ld * c, NULL)); /* B_{l-1} = P_l^T B_l */
     PMG_HIP(hipDeviceSynchronize());
     pmg_dev_free(Bcur);
     Bcur = Bnext;
     if (Cc->is_st27) { /* a sampled level (not the Cholesky level) */
       st27_det_ctx ctx = {h, Cc};
-      PMG_CALL(pmg_lrc_build_dev(&Cc->lrc, k, Cc->ld, Bcur, h->lrc_S, st27_det_sweep, &ctx, NULL, NULL));
+      PMG_CALL(pmg_lrc_build_dev(&Cc->lrc, k, Cc->ld, Bcur, h->lrc_S, st27_det_sweep, &ctx, Cc->distributed ? mg_reduce : NULL, h));
     }
   }
   /* coarsest block to the host, natural numbering (the padded layout minus its ghost planes) */
@@ -1166,6 +1180,7 @@ static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, 
       }
       if (Lv->lrc) PMG_CALL(pmg_lrc_rhs_done(Lv->lrc, stream));
       if (Lv->lrc) PMG_CALL(pmg_lrc_post(Lv->lrc, backward ? PMG_SOR_BACKWARD_SWEEP : PMG_SOR_FORWARD_SWEEP, Lv->x, stream)); /* src/mc_sor.c:101-112 */
+      if (Lv->lrc && Lv->distributed) PMG_CALL(halo_level(h, Lv, Lv->x, stream)); /* the repair changed boundary planes */
     }
   }
   return PMG_SUCCESS;
@@ -1177,10 +1192,61 @@ static uint64_t level_seed(uint64_t seed, int level) { return seed + 0x9E3779B97
 static pmg_status mg_smooth(pmg_mgmc h, int l, uint64_t seed, uint64_t *ctr, void *stream)
 {
   mg_level *Lv = &h->lv[l];
-  if (Lv->is_grid && h->dist) PMG_CALL(pmg_dist_sample_cvec(h->dist, Lv->b, Lv->x, h->nu, h->scaled, h->sweep_type, level_seed(seed, l), *ctr, ctr, stream)); /* leaves the ghost planes current */
+  if (Lv->is_grid && h->dist && Lv->lrc) { /* MATLRC on z-slabs: noise term, one slab sweep, repair, per directional sweep */
+    for (int it = 0; it < h->nu; ++it) {
+      const int ndir = h->sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
+      for (int d = 0; d < ndir; ++d) {
+        const int     dir = ndir == 2 ? (d == 0 ? PMG_SOR_FORWARD_SWEEP : PMG_SOR_BACKWARD_SWEEP) : h->sweep_type;
+        const double *rhs = Lv->b;
+        PMG_CALL(pmg_lrc_rhs(Lv->lrc, Lv->b, level_seed(seed, l), *ctr, &rhs, stream));
+        PMG_CALL(pmg_dist_sample_cvec(h->dist, rhs, Lv->x, 1, h->scaled, dir, level_seed(seed, l), *ctr, ctr, stream));
+        PMG_CALL(pmg_lrc_rhs_done(Lv->lrc, stream));
+        PMG_CALL(pmg_lrc_post(Lv->lrc, dir, Lv->x, stream));
+        PMG_CALL(halo_level(h, Lv, Lv->x, stream)); /* the repair changed boundary planes */
+      }
+    }
+  } else if (Lv->is_grid && h->dist) PMG_CALL(pmg_dist_sample_cvec(h->dist, Lv->b, Lv->x, h->nu, h->scaled, h->sweep_type, level_seed(seed, l), *ctr, ctr, stream)); /* leaves the ghost planes current */
   else if (Lv->is_grid) PMG_CALL(pmg_grid_sample_cvec(Lv->g, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
   else if (Lv->is_st27) PMG_CALL(st27_sample(h, Lv, h->nu, level_seed(seed, l), ctr, stream));
   else PMG_CALL(pmg_mcsor_sample_layout(Lv->mc, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
+  return PMG_SUCCESS;
+}
+
+/* b_coarse = P_l^T r_fine (MatRestrict).  A z-slab restricts into the coarse planes it owns (K with fine plane 2K on
+   this rank) and needs r on its ghost planes for that (one halo of r); into a replicated coarse level the owned part is
+   followed by an all-gather.  r_fine's ghost planes are overwritten. */
+static pmg_status mg_restrict(pmg_mgmc h, int l, double *r_fine, double *b_coarse, void *stream)
+{
+  mg_level      *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
+  pmgk_st27_dims CD   = level_dims(Cc);
+  double        *bc   = b_coarse;
+  const int      fold = Lv->distributed && !Cc->distributed; /* distributed -> replicated */
+  const int32_t *cc   = h->dist ? h->cuts + (size_t)(l - 1) * (size_t)(h->nranks + 1) : NULL;
+  if (Lv->distributed) PMG_CALL(halo_level(h, Lv, r_fine, stream));
+  if (fold) {
+    CD.kz0 = cc[h->rank];
+    CD.nz  = cc[h->rank + 1] - cc[h->rank];
+    bc     = b_coarse + Cc->off * CD.kz0; /* plane K of the full-size vector = plane K - kz0 of the shifted one */
+  }
+  if (Lv->grid_transfer) { /* matrix-free */
+    pmgk_grid_layout GL;
+    PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
+    PMG_KERNEL(pmgk_q1_restrict(&GL, &CD, Lv->cpos_dev, r_fine, bc, stream));
+  } else if (Lv->nat_transfer) {
+    const pmgk_st27_dims FD = level_dims(Lv);
+    PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, r_fine, bc, stream));
+  } else {
+    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, r_fine, b_coarse, 0, stream));
+  }
+  if (fold) {
+    int64_t offs[64], cnts[64];
+    PMG_CHECK(h->nranks <= 64, PMG_ERR_ARG_OUTOFRANGE, "too many ranks");
+    for (int r = 0; r < h->nranks; ++r) {
+      offs[r] = Cc->off * ((int64_t)cc[r] + 1);
+      cnts[r] = Cc->off * (int64_t)(cc[r + 1] - cc[r]);
+    }
+    PMG_CALL(pmg_dist_allgather(h->dist, b_coarse, offs, cnts, stream));
+  }
   return PMG_SUCCESS;
 }
 
@@ -1202,37 +1268,8 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* PCMGSetResidual(..., As[l]), src/pc_gamgmc.c:194 */
     }
     else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
-    /* a z-slab restricts into the coarse planes it owns (K with fine plane 2K on this rank) and needs r on its ghost
-       planes for that; into a replicated coarse level the owned part is followed by an all-gather */
-    pmgk_st27_dims CD   = level_dims(Cc);
-    double        *bc   = Cc->b;
-    const int      fold = Lv->distributed && !Cc->distributed; /* distributed -> replicated */
-    const int32_t *cc   = h->dist ? h->cuts + (size_t)(l - 1) * (size_t)(h->nranks + 1) : NULL;
-    if (Lv->distributed) PMG_CALL(halo_level(h, Lv, Lv->r, stream));
-    if (fold) {
-      CD.kz0 = cc[h->rank];
-      CD.nz  = cc[h->rank + 1] - cc[h->rank];
-      bc     = Cc->b + Cc->off * CD.kz0; /* plane K of the full-size vector = plane K - kz0 of the shifted one */
-    }
-    if (Lv->grid_transfer) { /* MatRestrict, matrix-free */
-      pmgk_grid_layout GL;
-      PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
-      PMG_KERNEL(pmgk_q1_restrict(&GL, &CD, Lv->cpos_dev, Lv->r, bc, stream));
-    } else if (Lv->nat_transfer) {
-      const pmgk_st27_dims FD = level_dims(Lv);
-      PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, Lv->r, bc, stream));
-    } else {
-      PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, Lv->r, Cc->b, 0, stream)); /* MatRestrict */
-    }
-    if (fold) {
-      int64_t offs[64], cnts[64];
-      PMG_CHECK(h->nranks <= 64, PMG_ERR_ARG_OUTOFRANGE, "too many ranks");
-      for (int r = 0; r < h->nranks; ++r) {
-        offs[r] = Cc->off * ((int64_t)cc[r] + 1);
-        cnts[r] = Cc->off * (int64_t)(cc[r + 1] - cc[r]);
-      }
-      PMG_CALL(pmg_dist_allgather(h->dist, Cc->b, offs, cnts, stream));
-    }
+    if (Lv->is_grid && Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* z-slabs: the update of the fine level lives here, not in the grid object */
+    PMG_CALL(mg_restrict(h, l, Lv->r, Cc->b, stream));
   }
   {
     mg_level *C0 = &h->lv[0];
@@ -1304,6 +1341,7 @@ pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32
     } else { /* w = b - A y; work = MG(w); y += work, src/pc_gamgmc.c:253-256 */
       if (F->is_grid) PMG_CALL(pmg_grid_residual_cvec(F->g, h->b_lay, h->y_lay, F->b, stream));
       else PMG_CALL(pmg_mcsor_residual_layout(F->mc, h->b_lay, h->y_lay, F->b, stream));
+      if (F->is_grid && F->lrc) PMG_CALL(pmg_lrc_residual_sub(F->lrc, h->y_lay, F->b, stream)); /* z-slabs */
       PMG_CALL(mg_vcycle(h, seed, counter0 + (uint64_t)it, 0, stream));
       PMG_KERNEL(pmgk_axpy(F->ld, 1.0, F->x, h->y_lay, stream));
     }

@@ -126,10 +126,13 @@ def _mg_worker(rank, world, port, grid, kappa, levels, opts, its, q, transport):
     mg.set_smoother(opts["scaled"], opts["omega"], opts["sweep"], opts["nu"])
     mg.set_coarse(opts["coarse"], opts["coarse_its"])
     mg.set_correction_form(opts["literal"])
+    lo, hi = mg.plane_range[0] * nx * ny, mg.plane_range[1] * nx * ny
+    if opts.get("lowrank"):
+        B, S = _ball_factors(grid)
+        mg.set_lowrank(B[lo:hi], S)  # this rank's rows of the observation vectors
     mg.setup()
     rng = np.random.default_rng(5)
     b_all, y_all = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
-    lo, hi = mg.plane_range[0] * nx * ny, mg.plane_range[1] * nx * ny
     b = torch.as_tensor(b_all[lo:hi], device="cuda")
     y = torch.as_tensor(y_all[lo:hi], device="cuda")
     seen = []
@@ -142,6 +145,18 @@ def _mg_worker(rank, world, port, grid, kappa, levels, opts, its, q, transport):
     dist.destroy_process_group()
 
 
+def _ball_factors(grid):
+    """three ball-indicator observation vectors (reference src/obs.c:39-50) straddling the slab faces"""
+    nx, ny, nz = grid
+    X, Y, Z = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), np.linspace(0, 1, nz), indexing="ij")
+    pts = np.stack([X.ravel(order="F"), Y.ravel(order="F"), Z.ravel(order="F")], 1)
+    B = np.zeros((nx * ny * nz, 3))
+    for c, (ctr, r) in enumerate([((0.3, 0.4, 0.5), 0.22), ((0.7, 0.6, 0.25), 0.2), ((0.5, 0.3, 0.8), 0.18)]):
+        inside = ((pts - np.asarray(ctr)) ** 2).sum(1) < r * r
+        B[inside, c] = 1.0 / inside.sum()
+    return B, np.array([40.0, 90.0, 60.0])
+
+
 MG_DEFAULT = dict(scaled=False, omega=1.0, sweep=1, nu=1, coarse="cholsampler", coarse_its=1, literal=False, env={})
 
 
@@ -151,7 +166,9 @@ MG_DEFAULT = dict(scaled=False, omega=1.0, sweep=1, nu=1, coarse="cholsampler", 
     ((33, 17, 33), 4, 4, {"env": {"PMG_MG_REPLICATE_BELOW": "2000"}, "scaled": True, "omega": 1.2, "sweep": 3, "nu": 2, "coarse": "gibbs", "coarse_its": 2}),
     ((17, 9, 33), 3, 2, {"env": {"PMG_MG_REPLICATE_BELOW": "100"}, "literal": True, "sweep": 2, "scaled": True}),
     ((9, 9, 33), 4, 5, {"env": {"PMG_MG_REPLICATE_BELOW": "50"}, "scaled": True, "sweep": 3}),  # three distributed levels; on the 9-plane level the ranks own 2,2,2,1,2 planes (5 ranks + this process = the box's limit of 6 GPU processes)
-], ids=["replicated", "slab_levels_3ranks", "symmetric_gibbs_coarse_4ranks", "literal_backward", "one_plane_per_rank_5ranks"])
+    ((17, 17, 33), 4, 3, {"env": {"PMG_MG_REPLICATE_BELOW": "400"}, "lowrank": True, "scaled": True, "sweep": 3}),  # config 5 across ranks: low-rank update on distributed and replicated levels
+    ((17, 17, 17), 3, 2, {"lowrank": True, "literal": True, "coarse": "gibbs", "coarse_its": 2, "scaled": True}),
+], ids=["replicated", "slab_levels_3ranks", "symmetric_gibbs_coarse_4ranks", "literal_backward", "one_plane_per_rank_5ranks", "lowrank_3ranks", "lowrank_literal_2ranks"])
 def test_distributed_vcycle_reproduces_the_single_device_chain(grid, levels, world, opts):
     """z-slab MGMC (pmg_mgmc_create_dmda_slab) with `world` ranks sharing the one GPU over the ipc transport: sweeps
     with per-phase halos, residual halo + restriction, all-gather into the replicated coarse part, prolongation onto
@@ -180,11 +197,17 @@ def test_distributed_vcycle_reproduces_the_single_device_chain(grid, levels, wor
     one.set_smoother(o["scaled"], o["omega"], o["sweep"], o["nu"])
     one.set_coarse(o["coarse"], o["coarse_its"])
     one.set_correction_form(o["literal"])
+    if o.get("lowrank"):
+        one.set_lowrank(*_ball_factors(grid))
     one.setup()
     yd = torch.as_tensor(y_all, device="cuda")
     want = []
     ctr = one.sample(torch.as_tensor(b_all, device="cuda"), yd, its, seed=42, counter0=1, callback=lambda it, yy: want.append(yy.cpu().numpy().copy()))
     assert all(x[2] == ctr for x in parts)
+    if o.get("lowrank"):  # the k-vectors B^T y are summed per rank, then over the ranks: equal to rounding, not bit for bit
+        got, ref = np.concatenate([x[1] for x in parts]), yd.cpu().numpy()
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-12
+        return
     for it in range(its - 1):  # every intermediate sample, as the callback saw it
         assert np.array_equal(np.concatenate([x[3][it] for x in parts]), want[it])
     assert np.array_equal(np.concatenate([x[1] for x in parts]), yd.cpu().numpy())
