@@ -123,44 +123,60 @@ def mgmc_secondary(n: int = 257, levels: int = 5, its: int = 20) -> dict:
     return {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample (sorgibbs 1+1, cholsampler on {(n - 1) // 2 ** (levels - 1) + 1}^3)", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "setup_s": setup_s, "model_GBps_at_160B_per_unknown": 160 * n ** 3 / ms / 1e6, "finite": bool(torch.isfinite(y).all().item())}
 
 
-def mgmc_lowrank_secondary(n: int = 257, levels: int = 5, k: int = 3, its: int = 20) -> dict:
-    """Secondary line (BASELINE config 5 on one GPU: "low-rank observation update on a 256^3 grid, dense coarse
-    Cholesky on MFMA"): the MGMC chain on A + B S B^T with k ball observations (reference src/obs.c:135-180,
+def mgmc_lowrank_secondary(rank: int = 0, world: int = 1, transport=None, share: bool = False, n: int = 257, levels: int = 5, k: int = 3, its: int = 20) -> dict:
+    """Secondary line (BASELINE config 5: "low-rank observation update on a 256^3 grid, dense coarse Cholesky on MFMA,
+    4 GPUs"): the MGMC chain on A + B S B^T with k ball observations (reference src/obs.c:135-180,
     examples/ex4.c:150-168: radii 0.1 / 0.15 / 0.1, sigma^2 = 1e-4) on every level of the 257^3 hierarchy, coarse
-    Cholesky of the explicit sum on 17^3.  Not the headline metric."""
+    Cholesky of the explicit sum on 17^3, on `world` z-slabs (strong scaling; each rank holds its rows of B).
+    Collective over all ranks.  Not the headline metric."""
     import numpy as np
     import torch
+    import torch.distributed as dist
 
-    from parmgmc_amd import MGMC
+    from parmgmc_amd.dist import DistMGMC
 
+    t0 = time.perf_counter()
+    mg = DistMGMC(n, n, n, 10.0, levels, rank, world, transport=transport)
+    k0, k1 = mg.plane_range
     xs = np.linspace(0, 1, n)
     centres = [(0.25, 0.25, 0.25), (0.75, 0.75, 0.75), (0.25, 0.75, 0.5)] + [(0.5, 0.5, 0.1 + 0.8 * q / max(1, k - 4)) for q in range(max(0, k - 3))]
     radii = ([0.1, 0.15, 0.1] + [0.08] * max(0, k - 3))[:k]
-    B = np.zeros((n ** 3, k))
+    B = np.zeros((n * n * (k1 - k0), k))  # this rank's planes only
     for c in range(k):
-        ix, iy, iz = (np.nonzero(np.abs(xs - centres[c][d]) < radii[c])[0] for d in range(3))
+        ix, iy = (np.nonzero(np.abs(xs - centres[c][d]) < radii[c])[0] for d in range(2))
+        iz = np.nonzero(np.abs(xs - centres[c][2]) < radii[c])[0]
+        iz = iz[(iz >= k0) & (iz < k1)]
+        if len(iz) == 0:
+            continue
         I, J, K = np.meshgrid(ix, iy, iz, indexing="ij")
         inside = (xs[I] - centres[c][0]) ** 2 + (xs[J] - centres[c][1]) ** 2 + (xs[K] - centres[c][2]) ** 2 < radii[c] ** 2
-        B[(I + n * (J + n * K))[inside], c] = (1.0 / (n - 1) ** 3) / (4.0 / 3.0 * np.pi * radii[c] ** 3)  # lumped mass / ball volume
+        B[(I + n * (J + n * (K - k0)))[inside], c] = (1.0 / (n - 1) ** 3) / (4.0 / 3.0 * np.pi * radii[c] ** 3)  # lumped mass / ball volume
     S = np.full(k, 1e4)
-    t0 = time.perf_counter()
-    mg = MGMC(n, n, n, 10.0, levels)
     mg.set_lowrank(B, S)
     mg.setup()
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     b = torch.as_tensor(B @ (S * np.resize([1.0, -1.0], k)), device="cuda")  # f = B S y_obs (src/obs.c:176-178)
     del B
-    y = torch.zeros(n ** 3, dtype=torch.float64, device="cuda")
+    y = torch.zeros(mg.n_local, dtype=torch.float64, device="cuda")
     ctr = mg.sample(b, y, 3, seed=0xCAFE)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
     mg.sample(b, y, its, seed=0xCAFE, counter0=ctr)
-    e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / its
-    return {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample on A + B S B^T, k = {k} ball observations on every level (row-compact B, Bb), cholsampler of the explicit sum on {(n - 1) // 2 ** (levels - 1) + 1}^3", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "setup_s": setup_s, "finite": bool(torch.isfinite(y).all().item())}
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cpu" if share else "cuda")
+    fin = torch.tensor([1.0 if bool(torch.isfinite(y).all().item()) else 0.0], dtype=torch.float64, device="cpu" if share else "cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+    ms = float(t.item()) / its * 1e3
+    res = {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample on A + B S B^T, k = {k} ball observations on every level (row-compact B, Bb), cholsampler of the explicit sum on {(n - 1) // 2 ** (levels - 1) + 1}^3, {world} z-slab(s)", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "n_gpus": world, "transport": mg.transport, "setup_s": setup_s, "finite": bool(fin.item() == 1.0)}
+    mg.destroy()
+    return res
 
 
 def unstructured_secondary(refine: int = 5, its: int = 50) -> dict:
@@ -409,11 +425,17 @@ def main() -> None:
         try:
             if world == 1:
                 out["secondary_mgmc"] = mgmc_secondary()
-                for key, fn in (("secondary_mgmc_lowrank", mgmc_lowrank_secondary), ("secondary_unstructured", unstructured_secondary)):
-                    try:
-                        out[key] = fn()
-                    except Exception as e:  # noqa: BLE001
-                        out[key] = {"error": f"{type(e).__name__}: {e}"}
+                try:
+                    out["secondary_unstructured"] = unstructured_secondary()
+                except Exception as e:  # noqa: BLE001
+                    out["secondary_unstructured"] = {"error": f"{type(e).__name__}: {e}"}
+            tr2 = used_transport if used_transport in ("ipc", "rccl") else None
+            try:
+                sec = mgmc_lowrank_secondary(rank, world, tr2, share)
+            except Exception as e:  # noqa: BLE001
+                sec = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                out["secondary_mgmc_lowrank"] = sec
             sec = mgmc_dist_secondary(rank, world, used_transport if used_transport in ("ipc", "rccl") else None, share, args.mgmc_n, args.mgmc_levels)
             if rank == 0:
                 out["secondary_mgmc_dist"] = sec
