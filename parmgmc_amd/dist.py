@@ -1,15 +1,17 @@
-"""Multi-GPU Gibbs sampling on a z-slab decomposition: one process per GPU, halo planes over RCCL/xGMI.
+"""Multi-GPU drivers: one process per GPU, torch.distributed for the bootstrap (and for the fall-back transport).
 
 Replaces the reference's MPI design -- row-block ownership of a MATMPIAIJ with one ghost VecScatter per colour
-(reference src/mc_sor.c:317-340, scatter plan :152-214) -- by: each rank owns nz/size consecutive grid planes
-(`slab_cuts`, PETSc's ownership rule), and before the points of colour c are swept the boundary planes of the
-OTHER colour are exchanged with the two z-neighbours.  In the colour-partitioned layout a plane of one colour
-is one contiguous block, so each exchange is a single send/recv per neighbour (no packing).  Because noise is a
-function of global indices only, the chain is bit-identical for every number of ranks.
+(reference src/mc_sor.c:317-340, scatter plan :152-214):
 
-The exchange goes through ``torch.distributed`` point-to-point ops (backend "nccl" = RCCL on GPU tensors;
-"gloo" on CPU tensors in the CPU tests).  torch is plumbing here: the sweeps are the HIP kernels behind the
-C-ABI.
+* ``DistGridSampler`` -- sorgibbs / mcgibbs on the DMDA operator, z-slabs (`slab_cuts`, PETSc's ownership rule).  The
+  sample loop is the C loop of pmg_dist.c over the "ipc" transport (peer stores + flag words, hand-shake inside the
+  sweep kernel) or RCCL send/recv (``IpcSlabDriver`` / ``RcclSlabDriver``); ``run_samples`` + ``SlabHalo`` is the same
+  schedule over torch.distributed point-to-point ops (RCCL tensors, or gloo through host memory in the CPU tests).
+* ``DistMGMC`` -- the Multigrid Monte Carlo V-cycle on z-slabs (pmg_mgmc_create_dmda_slab), incl. low-rank updates.
+* ``DistMCSOR`` -- general MATAIJ matrices by row blocks: per-colour device sweeps, ghost updates between them.
+
+Because noise is a function of global indices only, every chain is the single-device chain for any number of ranks.
+torch is plumbing here: the sweeps are the HIP kernels behind the C-ABI.
 """
 from __future__ import annotations
 
