@@ -138,25 +138,17 @@ def mgmc_lowrank_secondary(rank: int = 0, world: int = 1, transport=None, share:
     t0 = time.perf_counter()
     mg = DistMGMC(n, n, n, 10.0, levels, rank, world, transport=transport)
     k0, k1 = mg.plane_range
-    xs = np.linspace(0, 1, n)
+    from parmgmc_amd import make_observation_mats
+
     centres = [(0.25, 0.25, 0.25), (0.75, 0.75, 0.75), (0.25, 0.75, 0.5)] + [(0.5, 0.5, 0.1 + 0.8 * q / max(1, k - 4)) for q in range(max(0, k - 3))]
     radii = ([0.1, 0.15, 0.1] + [0.08] * max(0, k - 3))[:k]
-    B = np.zeros((n * n * (k1 - k0), k))  # this rank's planes only
-    for c in range(k):
-        ix, iy = (np.nonzero(np.abs(xs - centres[c][d]) < radii[c])[0] for d in range(2))
-        iz = np.nonzero(np.abs(xs - centres[c][2]) < radii[c])[0]
-        iz = iz[(iz >= k0) & (iz < k1)]
-        if len(iz) == 0:
-            continue
-        I, J, K = np.meshgrid(ix, iy, iz, indexing="ij")
-        inside = (xs[I] - centres[c][0]) ** 2 + (xs[J] - centres[c][1]) ** 2 + (xs[K] - centres[c][2]) ** 2 < radii[c] ** 2
-        B[(I + n * (J + n * (K - k0)))[inside], c] = (1.0 / (n - 1) ** 3) / (4.0 / 3.0 * np.pi * radii[c] ** 3)  # lumped mass / ball volume
-    S = np.full(k, 1e4)
+    # MakeObservationMats on this rank's planes (library routine, src/obs.c:135-180 restated for the DMDA)
+    B, S, f = make_observation_mats(n, n, n, np.asarray(centres[:k]).ravel(), radii, np.resize([1.0, -1.0], k), 1e-4, kz0=k0, nz_owned=k1 - k0)
     mg.set_lowrank(B, S)
     mg.setup()
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
-    b = torch.as_tensor(B @ (S * np.resize([1.0, -1.0], k)), device="cuda")  # f = B S y_obs (src/obs.c:176-178)
+    b = torch.as_tensor(f, device="cuda")  # f = B S y_obs (src/obs.c:176-178)
     del B
     y = torch.zeros(mg.n_local, dtype=torch.float64, device="cuda")
     ctr = mg.sample(b, y, 3, seed=0xCAFE)

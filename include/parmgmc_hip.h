@@ -310,6 +310,12 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *mg);
 /* ------------------------------------------------------------------------------------------------------ */
 pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t seed, uint64_t counter, void *stream);
 
+/* MakeObservationMats (src/obs.c:135-180) on the unit-cube DMDA: ball-average observations for the low-rank update.
+   Column i of B = (lumped mass h^dim) / (ball volume) inside the ball of radius radii[i] around coords[dim*i..],
+   S = 1/sigma2, f = B (S o obsvals) (f_host / obsvals may be NULL).  Host arrays; rows = the planes
+   [kz0, kz0+nz_owned) in natural order (a z-slab builds only its own rows); B is column-major with nobs columns. */
+pmg_status pmg_make_observation_mats_dmda(int32_t nx, int32_t ny, int32_t nzg, int32_t kz0, int32_t nz_owned, int32_t nobs, double sigma2, const double *coords, const double *radii, const double *obsvals, double *B_host, double *S_host, double *f_host);
+
 /* ---- chain diagnostics (host arrays, host arithmetic -- as in the reference) ---------------------------------- */
 /* Autocorrelation (src/iact.c:17-47): acf[0..n) of the scalar series x[0..n) via a zero-padded FFT */
 pmg_status pmg_autocorrelation(int64_t n, const double *x_host, double *acf_host);

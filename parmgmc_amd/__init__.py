@@ -6,5 +6,5 @@ tests and benchmarks; PyTorch is used by callers for device memory and streams, 
 There is no CPU fallback: importing :mod:`parmgmc_amd.capi` fails loudly when the library is missing.
 """
 from .capi import lib, library_path, check, PMGError  # noqa: F401
-from .wrappers import MCSOR, GridMCSOR, CholSampler, MGMC, vec_set_random_standard_normal, autocorrelation, iact, estimate_covariance_errors  # noqa: F401
+from .wrappers import MCSOR, GridMCSOR, CholSampler, MGMC, vec_set_random_standard_normal, autocorrelation, iact, estimate_covariance_errors, make_observation_mats  # noqa: F401
 from .capi import SOR_FORWARD_SWEEP, SOR_BACKWARD_SWEEP, SOR_SYMMETRIC_SWEEP, COLORING_GREEDY, COLORING_LEXLEVELS, COLORING_USER  # noqa: F401

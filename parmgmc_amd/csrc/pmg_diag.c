@@ -196,3 +196,45 @@ pmg_status pmg_estimate_covariance_errors(int32_t n, const int32_t *rowptr, cons
   free(w);
   return st;
 }
+
+/* MakeObservationMats (src/obs.c:135-180) on the unit-cube DMDA (the reference builds it on a DMPlex; its DMDA variant
+   is the sketch at :69-95): observation i is the average of the field over the ball of radius radii[i] around
+   coords[dim*i ..] -- column i of B = M u_i with u_i = 1/vol inside the ball (:39-50), vol = pi r^2 or 4/3 pi r^3
+   (:27-37), M the LUMPED mass of the uniform grid, h^dim, in place of the FE mass matrix (FE assembly is out of scope) --,
+   S = 1/sigma2 (:150), f = B (S o obsvals) (:160-178).  Rows are this rank's planes [kz0, kz0+nz_owned) in natural
+   order, so a z-slab run builds only its own rows.  Host arrays: B is (nx*ny*nz_owned) x nobs column-major. */
+pmg_status pmg_make_observation_mats_dmda(int32_t nx, int32_t ny, int32_t nzg, int32_t kz0, int32_t nz_owned, int32_t nobs, double sigma2, const double *coords, const double *radii, const double *obsvals, double *B_host, double *S_host, double *f_host)
+{
+  PMG_CHECK(coords && radii && B_host && S_host, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(nx >= 2 && ny >= 2 && nzg >= 1 && kz0 >= 0 && nz_owned >= 1 && kz0 + nz_owned <= nzg, PMG_ERR_ARG_OUTOFRANGE, "grid %d x %d x %d, planes [%d, %d)", nx, ny, nzg, kz0, kz0 + nz_owned);
+  PMG_CHECK(nobs >= 1 && nobs <= 64 && sigma2 > 0, PMG_ERR_ARG_OUTOFRANGE, "nobs = %d, sigma2 = %g", nobs, sigma2);
+  PMG_CHECK(!f_host || obsvals, PMG_ERR_ARG_NULL, "f needs the observed values");
+  const int     dim = nzg > 1 ? 3 : 2; /* DMGetCoordinateDim, :27-31 */
+  const double  pi = 3.14159265358979323846;
+  const int64_t n  = (int64_t)nx * ny * nz_owned;
+  const double  hx = 1.0 / (nx - 1), hy = 1.0 / (ny - 1), hz = dim == 3 ? 1.0 / (nzg - 1) : 1.0;
+  const double  mass = hx * hy * (dim == 3 ? hz : 1.0);
+  memset(B_host, 0, sizeof(double) * (size_t)n * (size_t)nobs);
+  for (int32_t o = 0; o < nobs; ++o) {
+    const double *p = coords + (size_t)dim * o, r = radii[o];
+    const double  vol = dim == 2 ? pi * r * r : 4 * pi / 3. * r * r * r;
+    double       *col = B_host + (size_t)n * o;
+    for (int32_t k = 0; k < nz_owned; ++k)
+      for (int32_t j = 0; j < ny; ++j)
+        for (int32_t i = 0; i < nx; ++i) {
+          double diff = (i * hx - p[0]) * (i * hx - p[0]) + (j * hy - p[1]) * (j * hy - p[1]);
+          if (dim == 3) diff += ((kz0 + k) * hz - p[2]) * ((kz0 + k) * hz - p[2]);
+          if (diff < r * r) col[i + (int64_t)nx * (j + (int64_t)ny * k)] = mass / vol; /* :46-47 */
+        }
+    S_host[o] = 1. / sigma2;
+  }
+  if (f_host) { /* f = B (S o y), :171-173 */
+    memset(f_host, 0, sizeof(double) * (size_t)n);
+    for (int32_t o = 0; o < nobs; ++o) {
+      const double  w = S_host[o] * obsvals[o];
+      const double *col = B_host + (size_t)n * o;
+      for (int64_t q = 0; q < n; ++q) f_host[q] += col[q] * w;
+    }
+  }
+  return PMG_SUCCESS;
+}

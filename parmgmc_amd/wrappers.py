@@ -380,3 +380,17 @@ def estimate_covariance_errors(rowptr, colidx, vals, samples, chains: int):
     errs = np.empty(spc)
     check(lib.pmg_estimate_covariance_errors(n, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, chains, spc, S.ctypes.data, errs.ctypes.data))
     return errs
+
+
+def make_observation_mats(nx, ny, nz, coords, radii, obsvals, sigma2, kz0=0, nz_owned=None):
+    """MakeObservationMats (reference src/obs.c:135-180) on the unit-cube DMDA: returns (B, S, f) as host arrays, rows =
+    the planes [kz0, kz0 + nz_owned) in natural order."""
+    nz_owned = nz if nz_owned is None else nz_owned
+    coords = np.ascontiguousarray(coords, np.float64).ravel()
+    radii = np.ascontiguousarray(radii, np.float64)
+    vals = np.ascontiguousarray(obsvals, np.float64)
+    k, n = len(radii), nx * ny * nz_owned
+    B = np.zeros((n, k), order="F")
+    S, f = np.zeros(k), np.zeros(n)
+    check(lib.pmg_make_observation_mats_dmda(nx, ny, nz, kz0, nz_owned, k, sigma2, coords.ctypes.data, radii.ctypes.data, vals.ctypes.data, B.ctypes.data, S.ctypes.data, f.ctypes.data))
+    return B, S, f

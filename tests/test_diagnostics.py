@@ -61,3 +61,29 @@ def test_covariance_errors_match_oracle_and_decay():
     assert np.all(got < 0.25)  # ~ sqrt(n / chains)
     # the metric of the oracle's single-chain helper (tests of the samplers use it) is the same formula
     assert abs(O.covariance_error(A, S[:chains]) - want[0]) < 1e-12
+
+
+def test_make_observation_mats_on_the_grid():
+    """MakeObservationMats (reference src/obs.c:135-180) restated for the DMDA: ball indicators x lumped mass / ball
+    volume, S = 1/sigma2, f = B (S o y); slab rows are a slice of the full matrix."""
+    from parmgmc_amd import make_observation_mats
+
+    nx, ny, nz = 17, 13, 9
+    coords = [0.25, 0.25, 0.5, 0.75, 0.6, 0.3]
+    radii, vals, s2 = [0.2, 0.25], [1.0, -2.0], 1e-3
+    B, S, f = make_observation_mats(nx, ny, nz, coords, radii, vals, s2)
+    X, Y, Z = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), np.linspace(0, 1, nz), indexing="ij")
+    pts = np.stack([X.ravel(order="F"), Y.ravel(order="F"), Z.ravel(order="F")], 1)
+    h3 = 1.0 / ((nx - 1) * (ny - 1) * (nz - 1))
+    for c in range(2):
+        inside = ((pts - np.asarray(coords[3 * c:3 * c + 3])) ** 2).sum(1) < radii[c] ** 2
+        want = np.where(inside, h3 / (4 * np.pi / 3 * radii[c] ** 3), 0.0)
+        assert np.allclose(B[:, c], want, rtol=1e-14, atol=0)
+        assert 0.5 < B[:, c].sum() < 1.3  # a ball average: the weights add up to about 1
+    assert np.array_equal(S, np.full(2, 1.0 / s2))
+    assert np.allclose(f, B @ (S * np.asarray(vals)), rtol=1e-14)
+    Bs, _, fs = make_observation_mats(nx, ny, nz, coords, radii, vals, s2, kz0=3, nz_owned=4)
+    assert np.array_equal(Bs, B[3 * nx * ny:7 * nx * ny]) and np.array_equal(fs, f[3 * nx * ny:7 * nx * ny])
+    # 2-D: area of the disc
+    B2, _, _ = make_observation_mats(33, 33, 1, [0.5, 0.5], [0.3], [1.0], 1.0)
+    assert abs(B2.sum() - 1.0) < 0.05
