@@ -52,6 +52,27 @@ def measured_traffic(n: int):
     return best
 
 
+def usable_cores() -> int:
+    """cores this process may actually use: scheduler affinity, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    # a GPU box shows all host cores but grants one GPU's share (16): without a visible limit, assume that share
+    return min(n, int(os.environ.get("PMG_BENCH_CPU_THREADS", "16")))
+
+
 def cpu_baseline(nsub: int = 256, nfull: int = 512, samples: int = 8) -> dict:
     """Serial reference path (one colour = lexicographic Gauss-Seidel, reference src/mc_sor.c:397-410,256-271;
     noise per reference src/parmgmc.c:99-110; RHS per src/pc_mcgibbs.c:119-128) on an nsub^3 sub-grid, 1 core,
@@ -85,6 +106,7 @@ def cpu_baseline(nsub: int = 256, nfull: int = 512, samples: int = 8) -> dict:
     try:
         cols = O.coloring_redblack(nsub, nsub, nsub)
         _nc, cptr, crows = O.color_lists(cols)
+        L.orc_set_num_threads(usable_cores())  # the box's CPU share, not every core the host shows
         threads = L.orc_num_threads()
         y2 = np.zeros(n)
         L.orc_gibbs_sample_colored_parallel(n, 2, cptr, crows, A.rowptr, A.colidx, A.vals, dp, idg, sd, 1.0, b, y2, w, 0xCAFE, 0)

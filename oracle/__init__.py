@@ -88,6 +88,8 @@ def _declare(L: C.CDLL) -> None:
     L.orc_gibbs_sample_colored_parallel.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p, _i32p, _f64p, _f64p, C.c_double, _f64p, _f64p, _f64p, C.c_uint64, C.c_uint64]
     L.orc_gibbs_sample_colored_parallel.restype = None
     L.orc_num_threads.restype = C.c_int
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    L.orc_set_num_threads.restype = None
     L.orc_potrf_lower.restype = C.c_int
     L.orc_potrf_lower.argtypes = [C.c_int, _f64p]
     L.orc_chol_sample.argtypes = [C.c_int, _f64p, _f64p, _f64p, _f64p]

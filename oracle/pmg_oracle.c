@@ -367,6 +367,16 @@ void orc_gibbs_sample_serial(int n, const int32_t *rowptr, const int32_t *colidx
    plain loops otherwise): rows of one colour are independent (reference src/mc_sor.c:256-271 over the rows of an IS),
    so each colour is one parallel loop -- what the reference does with one MPI rank per core.  Used by bench.py as the
    second CPU baseline (cores = the threads OpenMP reports). */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+  extern void omp_set_num_threads(int);
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP
