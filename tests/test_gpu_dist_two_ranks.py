@@ -48,14 +48,14 @@ def _worker(rank, world, port, nx, ny, nz, kappa, omega, sweep_type, its, q, tra
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sweep_type,world,transport", [(1, 2, None), (3, 3, None), (1, 2, "ipc"), (3, 3, "ipc"), (2, 4, "ipc")])
-def test_ranks_on_one_gpu_reproduce_the_single_device_chain(sweep_type, world, transport):
+@pytest.mark.parametrize("sweep_type,world,transport,nz", [(1, 2, None, 11), (3, 3, None, 11), (1, 2, "ipc", 11), (3, 3, "ipc", 11), (2, 4, "ipc", 11), (3, 5, "ipc", 6)], ids=["fwd-2-torch", "sym-3-torch", "fwd-2-ipc", "sym-3-ipc", "bwd-4-ipc", "sym-5-ipc-one-plane-slabs"])
+def test_ranks_on_one_gpu_reproduce_the_single_device_chain(sweep_type, world, transport, nz):
     import torch
     import torch.multiprocessing as mp
 
     from parmgmc_amd import GridMCSOR
 
-    nx, ny, nz, kappa, omega, its = 40, 18, 11, 1.5, 1.1, 3
+    nx, ny, kappa, omega, its = 40, 18, 1.5, 1.1, 3  # nz = 6 on 5 ranks: slabs of 2, 1, 1, 1, 1 planes (one plane = both faces)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
