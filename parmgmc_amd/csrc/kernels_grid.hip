@@ -43,6 +43,11 @@ __device__ __forceinline__ void st2_sys(double *p, d2 v)
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p) + 1, (unsigned long long)__double_as_longlong(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// "uniform base pointer + unsigned 32-bit BYTE offset": the form the backend turns into one global access with a scalar
+// base (saddr) and a 32-bit lane offset, without 64-bit address arithmetic on the vector unit
+__device__ __forceinline__ const double *at_bytes(const double *base, uint32_t byte_off) { return reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off); }
+__device__ __forceinline__ double       *at_bytes(double *base, uint32_t byte_off) { return reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off); }
+
 // wave-uniform double -> SGPR pair
 __device__ __forceinline__ double uniform(double v)
 {
@@ -129,19 +134,23 @@ __device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L,
 
   const bool    hasS = j > 0, hasN = j < L.ny - 1, hasD = kg > 0, hasU = kg < L.nzg - 1;
   const double  h2 = op.h2;
-  const int64_t line = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + 2 * t; // element (plane k, line j, m = 2t)
-  const double *yo   = y_other + line;
+  // element (plane k, line j, m = 2t).  The row part of the address is wave-uniform (one line per wavefront unless
+  // PACKED): row pointers live in SGPRs and every access is "scalar base + unsigned 32-bit lane offset" -- no 64-bit
+  // address arithmetic on the vector unit, which this kernel is bound by
+  const int64_t  rowoff = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx;
+  const uint32_t lo     = 16u * (uint32_t)t; // byte offset of m = 2t inside the row (a row is at most 2^28 points long)
+  const double  *yo_row = y_other + rowoff;
   // p=0: left(0)=m' 2t-1 (ed), right(0)=2t,   left(1)=2t,   right(1)=2t+1
   // p=1: left(0)=m' 2t,        right(0)=2t+1, left(1)=2t+1, right(1)=2t+2 (ed)
   const int    eo = p ? (2 * t + 2 < L.sx ? 2 : 1) : (t > 0 ? -1 : 0); // clamped lane-neighbour offset
-  const d2     Vc = ld2(yo);
-  const double ed = yo[eo];
-  const d2     oS = ld2(yo - (hasS ? L.sx : 0));
-  const d2     oN = ld2(yo + (hasN ? L.sx : 0));
+  const d2     Vc = ld2(at_bytes(yo_row, lo));
+  const double ed = *at_bytes(yo_row, lo + 8u * (uint32_t)eo);
+  const d2     oS = ld2(at_bytes(yo_row - (hasS ? L.sx : 0), lo));
+  const d2     oN = ld2(at_bytes(yo_row + (hasN ? L.sx : 0), lo));
   const int64_t inplane = (int64_t)j * L.sx + 2 * t; // offset inside one plane
-  const d2      oD = (HALO && k == 0 && halo.glo) ? ld2_sys(halo.glo + inplane) : ld2(yo - (hasD ? L.sp : 0));
-  const d2      oU = (HALO && k == L.nz - 1 && halo.ghi) ? ld2_sys(halo.ghi + inplane) : ld2(yo + (hasU ? L.sp : 0));
-  const d2     bb = ld2(b_own + line);
+  const d2      oD = (HALO && k == 0 && halo.glo) ? ld2_sys(halo.glo + inplane) : ld2(at_bytes(yo_row - (hasD ? L.sp : 0), lo));
+  const d2      oU = (HALO && k == L.nz - 1 && halo.ghi) ? ld2_sys(halo.ghi + inplane) : ld2(at_bytes(yo_row + (hasU ? L.sp : 0), lo));
+  const d2     bb = ld2(at_bytes(b_own + rowoff, lo));
 
   const double L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
   const bool   hasW0 = i0 > 0, hasE0 = i0 < L.nx - 1, hasE1 = i1 < L.nx - 1;
@@ -183,13 +192,13 @@ __device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L,
     r0 = idg0 * s0;
     r1 = idg1 * s1;
   } else {
-    const d2 yo2 = ld2(y_own + line);
+    const d2 yo2 = ld2(at_bytes(y_own + rowoff, lo));
     r0           = op.one_minus_omega * yo2.x + idg0 * s0;
     r1           = op.one_minus_omega * yo2.y + idg1 * s1;
   }
   // the slot of a non-existent second point (odd nx) is a pad slot of this line: keep it zero
   const d2 out = {r0, v1 ? r1 : 0.0};
-  *reinterpret_cast<d2 *>(y_own + line) = out;
+  *reinterpret_cast<d2 *>(at_bytes(y_own + rowoff, lo)) = out;
   if (HALO) {
     if (k == 0 && halo.plo) st2_sys(halo.plo + inplane, out);
     if (k == L.nz - 1 && halo.phi) st2_sys(halo.phi + inplane, out);
