@@ -295,17 +295,19 @@ __global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, 
   if (i0 >= L.nx) return;
   const bool    v1   = i1 < L.nx;
   const bool    hasS = j > 0, hasN = j < L.ny - 1, hasD = kg > 0, hasU = kg < L.nzg - 1;
-  const int64_t line = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + 2 * t;
-  const double *yo   = y + (int64_t)(1 - c) * L.cs + line;
-  const int     eo   = p ? (2 * t + 2 < L.sx ? 2 : 1) : (t > 0 ? -1 : 0);
-  const d2      Vc   = ld2(yo);
-  const double  ed   = yo[eo];
-  const d2      oS   = ld2(yo - (hasS ? L.sx : 0));
-  const d2      oN   = ld2(yo + (hasN ? L.sx : 0));
-  const d2      oD   = ld2(yo - (hasD ? L.sp : 0));
-  const d2      oU   = ld2(yo + (hasU ? L.sp : 0));
-  const d2      bb   = ld2(b + (int64_t)c * L.cs + line);
-  const d2      yy   = ld2(y + (int64_t)c * L.cs + line);
+  const int64_t  rowoff = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx; // scalar row bases + 32-bit lane byte offsets, as in the sweep
+  const uint32_t lo     = 16u * (uint32_t)t;
+  const int64_t  line   = rowoff + 2 * t;
+  const double  *yo_row = y + (int64_t)(1 - c) * L.cs + rowoff;
+  const int      eo     = p ? (2 * t + 2 < L.sx ? 2 : 1) : (t > 0 ? -1 : 0);
+  const d2       Vc     = ld2(at_bytes(yo_row, lo));
+  const double   ed     = *at_bytes(yo_row, lo + 8u * (uint32_t)eo);
+  const d2       oS     = ld2(at_bytes(yo_row - (hasS ? L.sx : 0), lo));
+  const d2       oN     = ld2(at_bytes(yo_row + (hasN ? L.sx : 0), lo));
+  const d2       oD     = ld2(at_bytes(yo_row - (hasD ? L.sp : 0), lo));
+  const d2       oU     = ld2(at_bytes(yo_row + (hasU ? L.sp : 0), lo));
+  const d2       bb     = ld2(at_bytes(b + (int64_t)c * L.cs + rowoff, lo));
+  const d2       yy     = ld2(at_bytes(y + (int64_t)c * L.cs + rowoff, lo));
   const double  L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
   const bool    hasW0 = i0 > 0, hasE0 = i0 < L.nx - 1, hasE1 = i1 < L.nx - 1;
   const int     nyz = (int)hasS + (int)hasN + (int)hasD + (int)hasU;
