@@ -23,6 +23,35 @@ namespace {
 
 __device__ __forceinline__ int pos_class(int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 2 : 1); }
 
+// "uniform base pointer + unsigned 32-bit byte offset": one global access with a scalar base, no 64-bit address
+// arithmetic on the vector unit (a level below the grid level has far fewer than 2^28 entries)
+__device__ __forceinline__ const double *at_bytes(const double *base, uint32_t byte_off) { return reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off); }
+
+// sum over the 26 neighbours of cf[e] * y[neighbour], branch-free: an absent neighbour is read at the centre (a valid
+// address) and enters with its table coefficient, which is an exact zero for out-of-domain offsets.  All 26 loads are
+// in flight together; with a branch per neighbour every load was waited for before the next one was issued.
+// ADD = false subtracts the products from `acc` one by one (the sweep's order), true adds them (the residual's).
+template <bool ADD>
+__device__ __forceinline__ double st27_neighbour_sum(const pmgk_st27 &S, int i, int j, int k, int32_t centre, const double *cf, const double *__restrict__ y, double acc)
+{
+  const int32_t sx = S.nx, sxy = S.nx * S.ny;
+  const bool    okx[3] = {i > 0, true, i < S.nx - 1}, oky[3] = {j > 0, true, j < S.ny - 1}, okz[3] = {k > 0, true, k < S.nzg - 1};
+  int           e      = 0;
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx, ++e) {
+        if (e == 13) continue; // the diagonal
+        const bool    ok  = okz[dz + 1] && oky[dy + 1] && okx[dx + 1];
+        const int32_t idx = ok ? centre + dx + sx * dy + sxy * dz : centre;
+        const double  v   = *at_bytes(y, 8u * (uint32_t)idx);
+        acc               = ADD ? acc + cf[e] * v : acc - cf[e] * v;
+      }
+  return acc;
+}
+
 template <bool NOISY>
 __global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int px, int py, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, double *y)
 {
@@ -53,21 +82,7 @@ __global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int 
     pmg::normal_pair((uint32_t)((uint64_t)row >> 1), 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
     sum = ((row & 1) ? z1 : z0) * s_sqrtd[cls] + sum;
   }
-  int e = 0;
-  for (int dz = -1; dz <= 1; ++dz) {
-    const int  kk  = k + dz;
-    const bool okz = kk >= 0 && kk < S.nzg;
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int  jj  = j + dy;
-      const bool oky = okz && jj >= 0 && jj < S.ny;
-      for (int dx = -1; dx <= 1; ++dx, ++e) {
-        if (e == 13) continue; // the diagonal
-        const int  i2 = i + dx;
-        const bool ok = oky && i2 >= 0 && i2 < S.nx;
-        if (ok) sum = sum - cf[e] * y[i2 + (int64_t)S.nx * (jj + (int64_t)S.ny * (kk - S.kz0 + 1))]; // CSR rows hold in-domain entries only
-      }
-    }
-  }
+  sum = st27_neighbour_sum<false>(S, i, j, k, (int32_t)lrow, cf, y, sum); // CSR rows hold in-domain entries only
   y[lrow] = one_minus_omega * y[lrow] + s_idiag[cls] * sum;
 }
 
@@ -81,15 +96,7 @@ __global__ __launch_bounds__(256) void st27_residual_kernel(pmgk_st27 S, const d
   if (j >= S.ny) return;
   const int64_t row = i + (int64_t)S.nx * (j + (int64_t)S.ny * (k - S.kz0 + 1));
   const double *cf  = s_coef + 27 * (pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nzg));
-  double        sum = 0.0;
-  int           e   = 0;
-  for (int dz = -1; dz <= 1; ++dz)
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx, ++e) {
-        if (e == 13) continue;
-        const int i2 = i + dx, jj = j + dy, kk = k + dz;
-        if (i2 >= 0 && i2 < S.nx && jj >= 0 && jj < S.ny && kk >= 0 && kk < S.nzg) sum = sum + cf[e] * y[i2 + (int64_t)S.nx * (jj + (int64_t)S.ny * (kk - S.kz0 + 1))];
-      }
+  double sum = st27_neighbour_sum<true>(S, i, j, k, (int32_t)row, cf, y, 0.0);
   sum    = sum + cf[13] * y[row];
   r[row] = b[row] - sum;
 }
