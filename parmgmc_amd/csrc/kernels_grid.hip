@@ -269,11 +269,38 @@ __global__ void grid_from_cvec_kernel(pmgk_grid_layout L, const double *__restri
   nat[i + (int64_t)L.nx * (j + (int64_t)L.ny * k)] = cv[(int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + (i >> 1)];
 }
 
-// r = b - A y on cvecs, one colour per launch, same tiling and XCD-banded order as the sweep.  Row sum in CSR
-// storage order INCLUDING the diagonal at its place (what PETSc MatMult does), then r = b - s
-// (VecAYPX(w,-1,b), reference src/pc_gamgmc.c:253-254).
+// r = b - A y on cvecs, BOTH colours in one launch (y is read from HBM once), same tiling and XCD-banded order as
+// the sweep: a thread owns the four consecutive grid points 4t .. 4t+3 of its line -- two of each colour, i.e. the 16-byte
+// slot m = 2t, 2t+1 of both colour arrays.  Row sum in CSR storage order INCLUDING the diagonal at its place (what
+// PETSc MatMult does), then r = b - s (VecAYPX(w,-1,b), reference src/pc_gamgmc.c:253-254).
+struct residual_consts {
+  double a, dA, dB, aS, aN, aD, aU;
+};
+
+__device__ __forceinline__ d2 residual_pair(const residual_consts &K, bool hasW0, bool hasE0, bool hasE1, bool v1, d2 oD, d2 oS, d2 oN, d2 oU, double L0, double R0, double L1, double R1, d2 yy, d2 bb)
+{
+  const double dg0 = (hasW0 && hasE0) ? K.dB : K.dA, dg1 = hasE1 ? K.dB : K.dA;
+  double       s0 = 0.0, s1 = 0.0;
+  s0 = s0 + K.aD * oD.x;
+  s1 = s1 + K.aD * oD.y;
+  s0 = s0 + K.aS * oS.x;
+  s1 = s1 + K.aS * oS.y;
+  s0 = s0 + (hasW0 ? K.a : 0.0) * L0;
+  s1 = s1 + K.a * L1;
+  s0 = s0 + dg0 * yy.x;
+  s1 = s1 + dg1 * yy.y;
+  s0 = s0 + (hasE0 ? K.a : 0.0) * R0;
+  s1 = s1 + (hasE1 ? K.a : 0.0) * R1;
+  s0 = s0 + K.aN * oN.x;
+  s1 = s1 + K.aN * oN.y;
+  s0 = s0 + K.aU * oU.x;
+  s1 = s1 + K.aU * oU.y;
+  const d2 out = {bb.x - s0, v1 ? bb.y - s1 : 0.0};
+  return out;
+}
+
 template <bool PACKED>
-__global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int bandw, int tplE, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+__global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, pmgk_grid_op op, int bandw, int tplE, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
 {
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int k  = blockIdx.z;
@@ -288,50 +315,36 @@ __global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, 
     t            = bx * 64 + threadIdx.x;
     j            = by * 4 + ty;
   }
-  if (j >= L.ny || 2 * t >= L.sx) return;
-  const int kg = k + L.kz0;
-  const int p  = (c + j + kg) & 1;
-  const int i0 = 4 * t + p, i1 = i0 + 2;
-  if (i0 >= L.nx) return;
-  const bool    v1   = i1 < L.nx;
-  const bool    hasS = j > 0, hasN = j < L.ny - 1, hasD = kg > 0, hasU = kg < L.nzg - 1;
+  if (j >= L.ny || 2 * t >= L.sx || 4 * t >= L.nx) return;
+  const int      kg   = k + L.kz0;
+  const int      ca   = (j + kg) & 1; // colour of the points 4t, 4t+2 (p = 0); the other colour owns 4t+1, 4t+3 (p = 1)
+  const bool     hasS = j > 0, hasN = j < L.ny - 1, hasD = kg > 0, hasU = kg < L.nzg - 1;
   const int64_t  rowoff = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx; // scalar row bases + 32-bit lane byte offsets, as in the sweep
   const uint32_t lo     = 16u * (uint32_t)t;
-  const int64_t  line   = rowoff + 2 * t;
-  const double  *yo_row = y + (int64_t)(1 - c) * L.cs + rowoff;
-  const int      eo     = p ? (2 * t + 2 < L.sx ? 2 : 1) : (t > 0 ? -1 : 0);
-  const d2       Vc     = ld2(at_bytes(yo_row, lo));
-  const double   ed     = *at_bytes(yo_row, lo + 8u * (uint32_t)eo);
-  const d2       oS     = ld2(at_bytes(yo_row - (hasS ? L.sx : 0), lo));
-  const d2       oN     = ld2(at_bytes(yo_row + (hasN ? L.sx : 0), lo));
-  const d2       oD     = ld2(at_bytes(yo_row - (hasD ? L.sp : 0), lo));
-  const d2       oU     = ld2(at_bytes(yo_row + (hasU ? L.sp : 0), lo));
-  const d2       bb     = ld2(at_bytes(b + (int64_t)c * L.cs + rowoff, lo));
-  const d2       yy     = ld2(at_bytes(y + (int64_t)c * L.cs + rowoff, lo));
-  const double  L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
-  const bool    hasW0 = i0 > 0, hasE0 = i0 < L.nx - 1, hasE1 = i1 < L.nx - 1;
-  const int     nyz = (int)hasS + (int)hasN + (int)hasD + (int)hasU;
-  const double  dA = table_at<PACKED>(op.diag, nyz + 1), dB = table_at<PACKED>(op.diag, nyz + 2);
-  const double  dg0 = (hasW0 && hasE0) ? dB : dA, dg1 = hasE1 ? dB : dA;
-  const double  a = -op.h2;
-  const double  aS = hasS ? a : 0.0, aN = hasN ? a : 0.0, aD = hasD ? a : 0.0, aU = hasU ? a : 0.0;
-  double        s0 = 0.0, s1 = 0.0;
-  s0 = s0 + aD * oD.x;
-  s1 = s1 + aD * oD.y;
-  s0 = s0 + aS * oS.x;
-  s1 = s1 + aS * oS.y;
-  s0 = s0 + (hasW0 ? a : 0.0) * L0;
-  s1 = s1 + a * L1;
-  s0 = s0 + dg0 * yy.x;
-  s1 = s1 + dg1 * yy.y;
-  s0 = s0 + (hasE0 ? a : 0.0) * R0;
-  s1 = s1 + (hasE1 ? a : 0.0) * R1;
-  s0 = s0 + aN * oN.x;
-  s1 = s1 + aN * oN.y;
-  s0 = s0 + aU * oU.x;
-  s1 = s1 + aU * oU.y;
-  const d2 out = {bb.x - s0, v1 ? bb.y - s1 : 0.0};
-  *reinterpret_cast<d2 *>(r + (int64_t)c * L.cs + line) = out;
+  const int64_t  offa = (int64_t)ca * L.cs + rowoff, offb = (int64_t)(1 - ca) * L.cs + rowoff;
+  const double  *ya = y + offa, *yb = y + offb;
+  const int64_t  dS = hasS ? L.sx : 0, dN = hasN ? L.sx : 0, dD = hasD ? L.sp : 0, dU = hasU ? L.sp : 0;
+  const d2       Ya = ld2(at_bytes(ya, lo)), Yb = ld2(at_bytes(yb, lo));
+  const double   edA = *at_bytes(yb, lo - (t > 0 ? 8u : 0u));              // west neighbour of point 4t: m = 2t-1 of the other colour
+  const double   edB = *at_bytes(ya, lo + (2 * t + 2 < L.sx ? 16u : 8u));  // east neighbour of point 4t+3: m = 2t+2
+  const int      nyz = (int)hasS + (int)hasN + (int)hasD + (int)hasU;
+  residual_consts K;
+  K.a  = -op.h2;
+  K.dA = table_at<PACKED>(op.diag, nyz + 1);
+  K.dB = table_at<PACKED>(op.diag, nyz + 2);
+  K.aS = hasS ? K.a : 0.0;
+  K.aN = hasN ? K.a : 0.0;
+  K.aD = hasD ? K.a : 0.0;
+  K.aU = hasU ? K.a : 0.0;
+  const int i0 = 4 * t;
+  { // colour ca: points i0, i0+2, neighbours in the other colour's array
+    const d2 out = residual_pair(K, i0 > 0, i0 < L.nx - 1, i0 + 2 < L.nx - 1, i0 + 2 < L.nx, ld2(at_bytes(yb - dD, lo)), ld2(at_bytes(yb - dS, lo)), ld2(at_bytes(yb + dN, lo)), ld2(at_bytes(yb + dU, lo)), edA, Yb.x, Yb.x, Yb.y, Ya, ld2(at_bytes(b + offa, lo)));
+    *reinterpret_cast<d2 *>(at_bytes(r + offa, lo)) = out;
+  }
+  if (i0 + 1 < L.nx) { // the other colour: points i0+1, i0+3
+    const d2 out = residual_pair(K, true, i0 + 1 < L.nx - 1, i0 + 3 < L.nx - 1, i0 + 3 < L.nx, ld2(at_bytes(ya - dD, lo)), ld2(at_bytes(ya - dS, lo)), ld2(at_bytes(ya + dN, lo)), ld2(at_bytes(ya + dU, lo)), Ya.x, Ya.y, Ya.y, edB, Yb, ld2(at_bytes(b + offb, lo)));
+    *reinterpret_cast<d2 *>(at_bytes(r + offb, lo)) = out;
+  }
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
@@ -409,10 +422,8 @@ extern "C" int pmgk_grid_residual(const pmgk_grid_layout *L, const pmgk_grid_op 
   const int  bandw = (!packed && nby >= 16) ? (nby + 7) / 8 : 0;
   const dim3 block(64, 4, 1);
   const dim3 grid = packed ? dim3((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, L->nz) : dim3(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, L->nz);
-  for (int c = 0; c < 2; ++c) {
-    if (packed) hipLaunchKernelGGL(grid_residual_kernel<true>, grid, block, 0, (hipStream_t)stream, *L, *op, c, bandw, tplE, b, y, r);
-    else hipLaunchKernelGGL(grid_residual_kernel<false>, grid, block, 0, (hipStream_t)stream, *L, *op, c, bandw, tplE, b, y, r);
-  }
+  if (packed) hipLaunchKernelGGL(grid_residual_kernel<true>, grid, block, 0, (hipStream_t)stream, *L, *op, bandw, tplE, b, y, r);
+  else hipLaunchKernelGGL(grid_residual_kernel<false>, grid, block, 0, (hipStream_t)stream, *L, *op, bandw, tplE, b, y, r);
   return launch_status();
 }
 

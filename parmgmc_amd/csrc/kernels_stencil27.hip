@@ -16,6 +16,7 @@
 // neighbours contributing an exact +0, and the noise is the row stream of the natural index, so results are
 // bit-identical to the sliced-ELL kernel on the assembled matrix.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "pmg_kernels.h"
 #include "pmg_rng.hpp"
 
@@ -146,6 +147,73 @@ __global__ __launch_bounds__(256) void st27_prolong_add_kernel(pmgk_st27_dims F,
   x[p]            = x[p] + s;
 }
 
+// the usual case (all three directions refined, < 2 GiB per vector): branch-free forms of the two kernels above -- a
+// fine point outside the domain is read at the centre with weight 0, an unused coarse neighbour with weight 0 at the
+// used one's address; same terms in the same order, so the same bits
+__global__ __launch_bounds__(256) void st27_restrict_full_kernel(pmgk_st27_dims F, pmgk_st27_dims C, const double *__restrict__ r, double *__restrict__ bc)
+{
+  const int flat = blockIdx.x * 256 + threadIdx.x, J = flat / C.nx, I = flat - J * C.nx, K = C.kz0 + blockIdx.z;
+  if (J >= C.ny) return;
+  const int32_t fnx = F.nx, fnxy = F.nx * F.ny;
+  const int     fi = 2 * I, fj = 2 * J, fk = 2 * K;
+  double        s  = 0.0;
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int     k    = fk + dz;
+    const bool    okz  = (unsigned)k < (unsigned)F.nzg;
+    const int32_t zoff = ((okz ? k : fk) - F.kz0 + 1) * fnxy;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int     j    = fj + dy;
+      const bool    oky  = (unsigned)j < (unsigned)F.ny;
+      const int32_t yoff = zoff + (oky ? j : fj) * fnx;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int     i   = fi + dx;
+        const bool    okx = (unsigned)i < (unsigned)F.nx;
+        const int32_t off = yoff + (okx ? i : fi);
+        const double  w0  = (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0);
+        const double  w   = (okx && oky && okz) ? w0 : 0.0;
+        s                 = s + w * *at_bytes(r, 8u * (uint32_t)off);
+      }
+    }
+  }
+  bc[I + (int64_t)C.nx * (J + (int64_t)C.ny * (K - C.kz0 + 1))] = s;
+}
+
+__global__ __launch_bounds__(256) void st27_prolong_add_full_kernel(pmgk_st27_dims F, pmgk_st27_dims C, int kbegin, const double *__restrict__ ec, double *__restrict__ x)
+{
+  const int flat = blockIdx.x * 256 + threadIdx.x, j = flat / F.nx, i = flat - j * F.nx, k = kbegin + blockIdx.z;
+  if (j >= F.ny) return;
+  const int32_t cnx = C.nx, cnxy = C.nx * C.ny;
+  const int     oddx = i & 1, oddy = j & 1, oddz = k & 1;
+  const int32_t base = ((k >> 1) - C.kz0 + 1) * cnxy + (j >> 1) * cnx + (i >> 1);
+  double        s    = 0.0;
+#pragma unroll
+  for (int cz = 0; cz < 2; ++cz) {
+    const double wz = oddz ? 0.5 : (cz ? 0.0 : 1.0);
+#pragma unroll
+    for (int by = 0; by < 2; ++by) {
+      const double wy = oddy ? 0.5 : (by ? 0.0 : 1.0);
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax) {
+        const double  wx  = oddx ? 0.5 : (ax ? 0.0 : 1.0);
+        const int32_t off = base + (cz & oddz) * cnxy + (by & oddy) * cnx + (ax & oddx);
+        s                 = s + (wx * wy * wz) * *at_bytes(ec, 8u * (uint32_t)off);
+      }
+    }
+  }
+  const int64_t p = i + (int64_t)F.nx * (j + (int64_t)F.ny * (k - F.kz0 + 1));
+  x[p]            = x[p] + s;
+}
+
+inline bool st27_transfer_full_case(const pmgk_st27_dims *F, const pmgk_st27_dims *C)
+{
+  static const int off = getenv("PMG_TRANSFER_GENERIC") != nullptr;
+  if (off || F->nx == C->nx || F->ny == C->ny || F->nzg == C->nzg) return false;
+  return (int64_t)F->nx * F->ny * (F->nz + 2) * 8 < ((int64_t)1 << 31);
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
@@ -186,6 +254,10 @@ extern "C" int pmgk_st27_residual(const pmgk_st27 *S, const double *b, const dou
 extern "C" int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims *C, const double *r, double *bc, void *stream)
 {
   if (C->nz <= 0) return 0;
+  if (st27_transfer_full_case(F, C)) {
+    hipLaunchKernelGGL(st27_restrict_full_kernel, dim3((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, C->nz), dim3(256), 0, (hipStream_t)stream, *F, *C, r, bc);
+    return launch_status();
+  }
   hipLaunchKernelGGL(st27_restrict_kernel, dim3((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, C->nz), dim3(256), 0, (hipStream_t)stream, *F, *C, r, bc);
   return launch_status();
 }
@@ -193,6 +265,10 @@ extern "C" int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims 
 extern "C" int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_dims *C, int kbegin, int kcount, const double *ec, double *x, void *stream)
 {
   if (kcount <= 0) return 0;
+  if (st27_transfer_full_case(F, C)) {
+    hipLaunchKernelGGL(st27_prolong_add_full_kernel, dim3((unsigned)(((int64_t)F->nx * F->ny + 255) / 256), 1, kcount), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, ec, x);
+    return launch_status();
+  }
   hipLaunchKernelGGL(st27_prolong_add_kernel, dim3((unsigned)(((int64_t)F->nx * F->ny + 255) / 256), 1, kcount), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, ec, x);
   return launch_status();
 }

@@ -1290,7 +1290,13 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       pmgk_grid_layout     GL;
       const pmgk_st27_dims CD = level_dims(Cc);
       PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
-      PMG_KERNEL(pmgk_q1_prolong_add(&GL, &CD, Lv->cpos_dev, -glo, Lv->nzl + glo + ghi, Cc->x, Lv->x, stream));
+      /* with omega = 1 a colour sweep never reads the old values of the colour it updates (the (1-omega) x term is
+         gone), so the colour the post-smoother visits first needs no correction: it is overwritten unread */
+      static int no_skip = -1;
+      if (no_skip < 0) no_skip = getenv("PMG_MG_PROLONG_BOTH") != NULL;
+      const int first = h->sweep_type == PMG_SOR_BACKWARD_SWEEP ? 1 : 0;
+      const int only  = (h->omega == 1.0 && h->nu >= 1 && !no_skip) ? 1 - first : -1;
+      PMG_KERNEL(pmgk_q1_prolong_add(&GL, &CD, Lv->cpos_dev, -glo, Lv->nzl + glo + ghi, only, Cc->x, Lv->x, stream));
     } else if (Lv->nat_transfer) {
       const pmgk_st27_dims FD = level_dims(Lv), CD = level_dims(Cc);
       PMG_KERNEL(pmgk_st27_prolong_add(&FD, &CD, Lv->kz0 - glo, Lv->nzl + glo + ghi, Cc->x, Lv->x, stream));
