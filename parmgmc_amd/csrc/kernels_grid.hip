@@ -112,19 +112,8 @@ __device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, un
 }
 
 template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED>
-__device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L, const pmgk_grid_op &op, int c, int nbx, int nby, int bandw, int k, int ty, const pmg::LogTabEntry *tab, const pmgk_grid_halo &halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+__device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L, const pmgk_grid_op &op, int c, int t, int j, int k, const pmg::LogTabEntry *tab, const pmgk_grid_halo &halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
 {
-  int       t, j;
-  if (PACKED) { // nbx = tplE here
-    const int flat = ((int)blockIdx.x * 4 + ty) * 64 + (int)threadIdx.x;
-    j              = flat / nbx;
-    t              = flat - j * nbx;
-  } else {
-    const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
-    t            = bx * 64 + threadIdx.x;
-    j            = by * 4 + ty;
-  }
   if (j >= L.ny || 2 * t >= L.sx) return;
   const int kg = k + L.kz0;
   const int p  = (c + j + kg) & 1;
@@ -205,18 +194,55 @@ __device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L,
   }
 }
 
-template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED>
-__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+// thread -> (t, line j) of its plane.  PACKED: the threads of a plane are numbered line after line with nbx = tplE
+// threads per line and dealt to the wavefronts without gaps; otherwise one line per wavefront, grid = (8*nbx, band, nz)
+// in XCD-banded order [the linear block id is blockIdx.x mod 8, so blockIdx.x & 7 is the XCD] or (nbx, nby, nz) plain
+template <bool PACKED>
+__device__ __forceinline__ void grid_thread_position(int nbx, int bandw, int ty, int &t, int &j)
+{
+  if (PACKED) {
+    const int flat = ((int)blockIdx.x * 4 + ty) * 64 + (int)threadIdx.x;
+    j              = flat / nbx;
+    t              = flat - j * nbx;
+  } else {
+    // banded: XCD x owns the lines [x*bandw, (x+1)*bandw) -- bands counted in LINES, so that 8 bands of ceil(ny/8)
+    // lines differ by less than one line tile (513 lines: 65 per XCD instead of 17 tiles = 68)
+    const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int jl = (int)blockIdx.y * 4 + ty;
+    t            = bx * 64 + threadIdx.x;
+    j            = bandw > 0 ? (jl < bandw ? (int)(blockIdx.x & 7u) * bandw + jl : 0x40000000) : jl;
+  }
+}
+
+// TAIL (lines of 64 m + a few threads -- the multigrid sizes 2^k+1 have tplE = 64 m + 1): the first `tmain` threads of
+// every line run in the one-line-per-wavefront mapping with all lanes busy, and the `tailw` threads left over per line
+// are collected, 256 per block, in extra blocks behind the last plane (blockIdx.z >= kcount) instead of occupying one
+// nearly empty wavefront per line.  Same arithmetic per point and noise addressed by grid position, so the mapping does
+// not change the results.
+template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED, bool TAIL>
+__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, int kcount, int tmain, int tailw, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
 {
   // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
   // wave-uniform; readfirstlane tells the compiler, which then keeps the boundary logic on the scalar unit
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
   __shared__ pmg::LogTabEntry s_logtab[NOISY ? 4 * PMG_LOGTAB_SIZE : 1];
   const pmg::LogTabEntry     *tab = s_logtab + (NOISY ? ty * PMG_LOGTAB_SIZE : 0);
+  int                         t, j;
+  if (TAIL && (int)blockIdx.z >= kcount) {
+    const int tb  = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * ((int)blockIdx.z - kcount));
+    const int per = (L.ny * tailw + 255) / 256; // tail blocks per plane
+    const int kz = tb / per, part = tb - kz * per;
+    if (kz >= kcount) return;
+    if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x);
+    const int f = (part * 4 + ty) * 64 + (int)threadIdx.x;
+    j           = f / tailw;
+    t           = tmain + f - j * tailw;
+    grid_color_sweep_body<NOISY, OMEGA1, false, true>(L, op, c, t, j, kbegin + kz * kstride, tab, halo, b_own, y_other, y_own);
+    return;
+  }
   if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x);
+  grid_thread_position<PACKED>(nbx, bandw, ty, t, j);
 
-  // grid = (8*nbx, band, nz) in XCD-banded order [the linear block id is blockIdx.x mod 8, so blockIdx.x & 7
-  // is the XCD], or (nbx, nby, nz) in plain order
   int k = kbegin + (int)blockIdx.z * kstride;
   if (HALO && halo.full) { // face planes first: they carry the halo traffic
     const int z = (int)blockIdx.z;
@@ -224,7 +250,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
     const bool face_lo = k == 0, face_hi = k == L.nz - 1;
     if (face_lo && halo.wlo) wave_wait_flag(halo.wlo, halo.wval, halo.err);
     if (face_hi && halo.whi) wave_wait_flag(halo.whi, halo.wval, halo.err);
-    grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, nbx, nby, bandw, k, ty, tab, halo, b_own, y_other, y_own);
+    grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, t, j, k, tab, halo, b_own, y_other, y_own);
     if (face_lo || face_hi) { // every block of a face plane reports; the last one tells the neighbours
       // the peer stores are system-scope write-through stores (st2_sys): waiting for their completion is all a
       // wavefront has to do -- a system-scope release FENCE here would also write the whole L2 back, once per
@@ -245,7 +271,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
     }
     return;
   }
-  grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, nbx, nby, bandw, k, ty, tab, halo, b_own, y_other, y_own);
+  grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, t, j, k, tab, halo, b_own, y_other, y_own);
 }
 
 // natural (DMDA, i fastest) <-> colour-partitioned storage
@@ -300,21 +326,8 @@ __device__ __forceinline__ d2 residual_pair(const residual_consts &K, bool hasW0
 }
 
 template <bool PACKED>
-__global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, pmgk_grid_op op, int bandw, int tplE, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+__device__ __forceinline__ void grid_residual_body(const pmgk_grid_layout &L, const pmgk_grid_op &op, int t, int j, int k, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
 {
-  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const int k  = blockIdx.z;
-  int       t, j;
-  if (PACKED) {
-    const int flat = ((int)blockIdx.x * 4 + ty) * 64 + (int)threadIdx.x;
-    j              = flat / tplE;
-    t              = flat - j * tplE;
-  } else {
-    const int bx = bandw > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int by = bandw > 0 ? (int)(blockIdx.x & 7u) * bandw + (int)blockIdx.y : (int)blockIdx.y;
-    t            = bx * 64 + threadIdx.x;
-    j            = by * 4 + ty;
-  }
   if (j >= L.ny || 2 * t >= L.sx || 4 * t >= L.nx) return;
   const int      kg   = k + L.kz0;
   const int      ca   = (j + kg) & 1; // colour of the points 4t, 4t+2 (p = 0); the other colour owns 4t+1, 4t+3 (p = 1)
@@ -347,6 +360,24 @@ __global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, 
   }
 }
 
+template <bool PACKED, bool TAIL>
+__global__ __launch_bounds__(256) void grid_residual_kernel(pmgk_grid_layout L, pmgk_grid_op op, int bandw, int tplE, int tmain, int tailw, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+{
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (TAIL && (int)blockIdx.z >= L.nz) { // the threads left over per line, 256 per block (see the sweep kernel)
+    const int tb  = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * ((int)blockIdx.z - L.nz));
+    const int per = (L.ny * tailw + 255) / 256;
+    const int kz = tb / per, part = tb - kz * per;
+    if (kz >= L.nz) return;
+    const int f = (part * 4 + ty) * 64 + (int)threadIdx.x, j = f / tailw;
+    grid_residual_body<true>(L, op, tmain + f - j * tailw, j, kz, b, y, r);
+    return;
+  }
+  int t, j;
+  grid_thread_position<PACKED>(tplE, bandw, ty, t, j);
+  grid_residual_body<PACKED>(L, op, t, j, (int)blockIdx.z, b, y, r);
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
@@ -367,29 +398,60 @@ static inline bool grid_use_packed(const pmgk_grid_layout *L)
   return 2 * lanes >= 3 * tplE;
 }
 
-template <bool NOISY, bool OMEGA1, bool HALO>
-static void launch_sweep(bool packed, dim3 grid, dim3 block, hipStream_t s, const pmgk_grid_layout &L, const pmgk_grid_op &op, int color, int nbx, int nby, int bandw, int kbegin, int kstride, const pmgk_grid_halo &h, const double *bo, const double *yo, double *ys)
+// how one plane's threads are dealt to the wavefronts
+struct grid_mapping {
+  bool packed, tail;
+  int  nbx, nby, bandw, tmain, tailw, ztail;
+  dim3 grid;
+};
+
+static grid_mapping grid_choose_mapping(const pmgk_grid_layout *L, int kcount, bool allow_tail)
 {
-  if (packed) hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, true>), grid, block, 0, s, L, op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
-  else hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, false>), grid, block, 0, s, L, op, color, nbx, nby, bandw, kbegin, kstride, h, bo, yo, ys);
+  static int banded_env = -1, tail_env = -1;
+  if (banded_env < 0) {
+    const char *e = getenv("PMG_GRID_BANDED");
+    banded_env    = e ? atoi(e) : 1;
+    e             = getenv("PMG_GRID_TAIL");
+    tail_env      = e ? atoi(e) : 1;
+  }
+  grid_mapping M;
+  const int    tpl = L->sx / 2, tplE = grid_threads_per_line(L);
+  M.nby   = (L->ny + 3) / 4;
+  M.tmain = tplE / 64 * 64;
+  M.tailw = tplE - M.tmain;
+  // a few threads more than full wavefronts per line: full wavefronts + collected tails
+  M.tail   = allow_tail && tail_env && M.tmain > 0 && M.tailw > 0 && M.tailw <= 8;
+  M.packed = !M.tail && grid_use_packed(L);
+  M.nbx    = M.packed ? tplE : (M.tail ? M.tmain / 64 : (tpl + 63) / 64);
+  // XCD-banded dispatch order needs enough line tiles to give every XCD a band
+  M.bandw = (!M.packed && banded_env && M.nby >= 16) ? (L->ny + 7) / 8 : 0; // lines per XCD band
+  M.ztail = 0;
+  if (M.packed) M.grid = dim3((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, kcount);
+  else {
+    const unsigned gx = M.bandw > 0 ? 8 * M.nbx : M.nbx, gy = M.bandw > 0 ? (M.bandw + 3) / 4 : M.nby;
+    if (M.tail) {
+      const int64_t nblocks = (int64_t)kcount * (((int64_t)L->ny * M.tailw + 255) / 256);
+      M.ztail               = (int)((nblocks + (int64_t)gx * gy - 1) / ((int64_t)gx * gy));
+    }
+    M.grid = dim3(gx, gy, kcount + M.ztail);
+  }
+  if (!M.tail) M.tmain = M.tailw = 0;
+  return M;
+}
+
+template <bool NOISY, bool OMEGA1, bool HALO>
+static void launch_sweep(const grid_mapping &M, dim3 block, hipStream_t s, const pmgk_grid_layout &L, const pmgk_grid_op &op, int color, int kbegin, int kstride, int kcount, const pmgk_grid_halo &h, const double *bo, const double *yo, double *ys)
+{
+  if (M.packed) hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, true, false>), M.grid, block, 0, s, L, op, color, M.nbx, M.nby, M.bandw, kbegin, kstride, kcount, 0, 0, h, bo, yo, ys);
+  else if (!HALO && M.tail) hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, false, false, true>), M.grid, block, 0, s, L, op, color, M.nbx, M.nby, M.bandw, kbegin, kstride, kcount, M.tmain, M.tailw, h, bo, yo, ys);
+  else hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, false, false>), M.grid, block, 0, s, L, op, color, M.nbx, M.nby, M.bandw, kbegin, kstride, kcount, 0, 0, h, bo, yo, ys);
 }
 
 extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, int kstride, const pmgk_grid_halo *halo, const double *b, double *y, void *stream)
 {
   if (kcount <= 0) return 0;
-  const int  tpl    = L->sx / 2; // threads per line
-  const bool packed = grid_use_packed(L);
-  const int  tplE   = grid_threads_per_line(L);
-  const int  nbx = packed ? tplE : (tpl + 63) / 64, nby = (L->ny + 3) / 4;
-  static int banded_env = -1;
-  if (banded_env < 0) {
-    const char *e = getenv("PMG_GRID_BANDED");
-    banded_env    = e ? atoi(e) : 1;
-  }
-  // XCD-banded dispatch order needs enough line tiles to give every XCD a band
-  const int  bandw = (!packed && banded_env && nby >= 16) ? (nby + 7) / 8 : 0;
-  const dim3 block(64, 4, 1);
-  const dim3 grid = packed ? dim3((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, kcount) : dim3(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, kcount);
+  const grid_mapping M = grid_choose_mapping(L, kcount, !halo);
+  const dim3         block(64, 4, 1);
   hipStream_t   s  = (hipStream_t)stream;
   const double *bo = b + (int64_t)color * L->cs, *yo = y + (int64_t)(1 - color) * L->cs;
   double       *ys = y + (int64_t)color * L->cs;
@@ -397,33 +459,31 @@ extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_
   memset(&h0, 0, sizeof h0);
   if (halo) {
     if (op->noisy) {
-      if (op->omega_is_one) launch_sweep<true, true, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);
-      else launch_sweep<true, false, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);
+      if (op->omega_is_one) launch_sweep<true, true, true>(M, block, s, *L, *op, color, kbegin, kstride, kcount, *halo, bo, yo, ys);
+      else launch_sweep<true, false, true>(M, block, s, *L, *op, color, kbegin, kstride, kcount, *halo, bo, yo, ys);
     } else {
-      if (op->omega_is_one) launch_sweep<false, true, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);
-      else launch_sweep<false, false, true>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, *halo, bo, yo, ys);
+      if (op->omega_is_one) launch_sweep<false, true, true>(M, block, s, *L, *op, color, kbegin, kstride, kcount, *halo, bo, yo, ys);
+      else launch_sweep<false, false, true>(M, block, s, *L, *op, color, kbegin, kstride, kcount, *halo, bo, yo, ys);
     }
   } else if (op->noisy) {
-    if (op->omega_is_one) launch_sweep<true, true, false>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
-    else launch_sweep<true, false, false>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
+    if (op->omega_is_one) launch_sweep<true, true, false>(M, block, s, *L, *op, color, kbegin, kstride, kcount, h0, bo, yo, ys);
+    else launch_sweep<true, false, false>(M, block, s, *L, *op, color, kbegin, kstride, kcount, h0, bo, yo, ys);
   } else {
-    if (op->omega_is_one) launch_sweep<false, true, false>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
-    else launch_sweep<false, false, false>(packed, grid, block, s, *L, *op, color, nbx, nby, bandw, kbegin, kstride, h0, bo, yo, ys);
+    if (op->omega_is_one) launch_sweep<false, true, false>(M, block, s, *L, *op, color, kbegin, kstride, kcount, h0, bo, yo, ys);
+    else launch_sweep<false, false, false>(M, block, s, *L, *op, color, kbegin, kstride, kcount, h0, bo, yo, ys);
   }
   return launch_status();
 }
 
 extern "C" int pmgk_grid_residual(const pmgk_grid_layout *L, const pmgk_grid_op *op, const double *b, const double *y, double *r, void *stream)
 {
-  const int  tpl    = L->sx / 2;
-  const bool packed = grid_use_packed(L);
-  const int  tplE   = grid_threads_per_line(L);
-  const int  nbx = (tpl + 63) / 64, nby = (L->ny + 3) / 4;
-  const int  bandw = (!packed && nby >= 16) ? (nby + 7) / 8 : 0;
-  const dim3 block(64, 4, 1);
-  const dim3 grid = packed ? dim3((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, L->nz) : dim3(bandw > 0 ? 8 * nbx : nbx, bandw > 0 ? bandw : nby, L->nz);
-  if (packed) hipLaunchKernelGGL(grid_residual_kernel<true>, grid, block, 0, (hipStream_t)stream, *L, *op, bandw, tplE, b, y, r);
-  else hipLaunchKernelGGL(grid_residual_kernel<false>, grid, block, 0, (hipStream_t)stream, *L, *op, bandw, tplE, b, y, r);
+  if (L->nz <= 0) return 0;
+  const grid_mapping M = grid_choose_mapping(L, L->nz, true);
+  const dim3         block(64, 4, 1);
+  const int          tplE = grid_threads_per_line(L);
+  if (M.packed) hipLaunchKernelGGL((grid_residual_kernel<true, false>), M.grid, block, 0, (hipStream_t)stream, *L, *op, M.bandw, tplE, 0, 0, b, y, r);
+  else if (M.tail) hipLaunchKernelGGL((grid_residual_kernel<false, true>), M.grid, block, 0, (hipStream_t)stream, *L, *op, M.bandw, tplE, M.tmain, M.tailw, b, y, r);
+  else hipLaunchKernelGGL((grid_residual_kernel<false, false>), M.grid, block, 0, (hipStream_t)stream, *L, *op, M.bandw, tplE, 0, 0, b, y, r);
   return launch_status();
 }
 

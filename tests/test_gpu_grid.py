@@ -22,9 +22,11 @@ def host(t):
 
 
 GRIDS = [(9, 9, 1, 10.0), (5, 5, 5, 10.0), (6, 5, 4, 2.0), (2, 2, 2, 1.0), (3, 1, 1, 1.0), (33, 7, 3, 0.5), (64, 6, 5, 10.0), (70, 3, 2, 1.0), (128, 128, 1, 1e-4)]
+# lines of 64 m + a few threads (the multigrid sizes 2^k+1): full wavefronts + collected tail threads, kernels_grid.hip
+TAIL_GRIDS = [(257, 5, 3, 10.0), (261, 3, 2, 1.0), (287, 2, 1, 0.5), (513, 2, 2, 2.0), (257, 70, 2, 1.0)]
 
 
-@pytest.mark.parametrize("grid", GRIDS)
+@pytest.mark.parametrize("grid", GRIDS + TAIL_GRIDS)
 @pytest.mark.parametrize("om", [1.0, 1.2])
 def test_deterministic_sweep_is_bit_exact(grid, om):
     """MCSORApply: fwd / bwd / sym on the HIP path == reference loop (src/mc_sor.c:256-289), bit for bit."""
@@ -91,7 +93,7 @@ def test_cvec_roundtrip_and_padding():
         assert np.count_nonzero(h) == x.size and np.isclose(np.sort(h[h != 0]), np.sort(x)).all()
 
 
-@pytest.mark.parametrize("grid", [(9, 9, 1, 10.0), (6, 5, 4, 2.0), (33, 7, 3, 0.5), (70, 3, 2, 1.0), (128, 128, 1, 10.0)])  # the last one is BASELINE config 0 (ex1.c at 128x128)
+@pytest.mark.parametrize("grid", [(9, 9, 1, 10.0), (6, 5, 4, 2.0), (33, 7, 3, 0.5), (70, 3, 2, 1.0), (128, 128, 1, 10.0)] + TAIL_GRIDS[:4])  # (128, 128, 1) is BASELINE config 0 (ex1.c at 128x128)
 def test_noisy_chain_matches_oracle(grid):
     """PCApplyRichardson_MulticolorGibbs / _SORGibbs sample loop with in-kernel Philox + Box-Muller noise vs
     the oracle (libm log/cos/sin): tolerance 1e-13 relative to max|y| (device log/sincospi differ from glibc in
@@ -236,3 +238,25 @@ def test_plane_range_sweeps_compose_to_the_full_sweep():
     with pytest.raises(PMGError) as e:
         g.sweep_color_planes_cvec(0, 5, 9, bc, y2)
     assert e.value.code == 63
+
+
+@pytest.mark.parametrize("grid", [(6, 5, 4, 2.0), (70, 3, 2, 1.0), (64, 6, 5, 10.0)] + TAIL_GRIDS)
+def test_residual_of_both_colours_matches_csr_product(grid):
+    """r = b - A y (PCMG's residual, src/pc_gamgmc.c:253-254) from the one-launch kernel that handles both colours:
+    row sums in CSR storage order, so bit-identical to the sequential CSR product."""
+    from parmgmc_amd import GridMCSOR
+
+    nx, ny, nz, kappa = grid
+    A = O.shifted_laplace(nx, ny, nz, kappa)
+    rng = np.random.default_rng(nx + ny)
+    b, y = rng.standard_normal(A.n), rng.standard_normal(A.n)
+    g = GridMCSOR(nx, ny, nz, kappa)
+    r = g.new_cvec()
+    g.residual_cvec(g.to_cvec(dev(b)), g.to_cvec(dev(y)), r)
+    want = np.empty(A.n)
+    for i in range(A.n):  # sequential row sums, storage order
+        s = 0.0
+        for q in range(A.rowptr[i], A.rowptr[i + 1]):
+            s = s + A.vals[q] * y[A.colidx[q]]
+        want[i] = b[i] - s
+    assert np.array_equal(host(g.from_cvec(r)), want), np.abs(host(g.from_cvec(r)) - want).max()
