@@ -47,7 +47,7 @@ def measured_traffic(n: int):
         if d.get("n") != n:
             continue
         for k in d["kernels"]:
-            if "grid_color_sweep_kernel<true, true>" in k["kernel"] and k.get("hbm_bytes_per_launch"):
+            if k["kernel"].startswith("grid_color_sweep_kernel<true, true, false") and k.get("hbm_bytes_per_launch"):  # NOISY, OMEGA1, no halo
                 best = (k["hbm_bytes_per_launch"], f.name)
     return best
 
@@ -275,8 +275,8 @@ def mgmc_dist_secondary(rank: int, world: int, transport, share: bool, n: int = 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=100, help="untimed steps; the first ~50 steps after idle run up to 40 %% slower while the clocks settle")
     ap.add_argument("--grid-n", dest="n", type=int, default=512, help="grid points per direction (default: the BASELINE 512^3)")
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

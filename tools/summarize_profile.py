@@ -2,7 +2,10 @@
 """Condenses rocprofv3 output directories (kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE) of one
 bench.py command into a small JSON + CSV summary that is committed under profiles/.
 
-usage: summarize_profile.py <trace_dir> <pmc_fetch_dir> <pmc_write_dir> <out_prefix> [n]
+usage: summarize_profile.py <trace_dir> <pmc_fetch_dir> <pmc_write_dir> <out_prefix> [n] [timed_launches]
+
+timed_launches: the last that many launches of the dominant kernel are bench.py's timed region (2 per step); their
+average is reported next to the all-launch average of --stats, which also contains the warm-up launches.
 
 HBM traffic follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports exactly half of the bytes of a wide coalesced streaming read, so the read side is doubled.  The
@@ -26,6 +29,12 @@ def load_counter(d, counter):
 def main():
     trace, fetch, write, out = sys.argv[1:5]
     n = int(sys.argv[5]) if len(sys.argv) > 5 else 512
+    timed = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    durations = defaultdict(list)
+    if timed:
+        for f in glob.glob(f"{trace}/**/*_kernel_trace.csv", recursive=True):
+            for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"])):
+                durations[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     stats = []
     for f in glob.glob(f"{trace}/**/*_kernel_stats.csv", recursive=True):
         stats += list(csv.DictReader(open(f)))
@@ -38,6 +47,10 @@ def main():
         f_kib = sum(fe[name]) / len(fe[name]) if fe.get(name) else None
         w_kib = sum(wr[name]) / len(wr[name]) if wr.get(name) else None
         rows.append({"kernel": short, "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"]), "FETCH_SIZE_KiB_raw": f_kib, "WRITE_SIZE_KiB": w_kib})
+        if timed and len(durations.get(name, [])) >= timed and "grid_color_sweep" in name:
+            last = durations[name][-timed:]
+            rows[-1]["timed_region_launches"] = timed
+            rows[-1]["timed_region_avg_us"] = sum(last) / len(last)
     # calibration of the gfx950 FETCH_SIZE correction on a kernel with a known read volume
     cal = next((x for x in rows if "grid_to_cvec" in x["kernel"] and x["FETCH_SIZE_KiB_raw"]), None)
     corr = 2.0
