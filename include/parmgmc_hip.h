@@ -395,6 +395,15 @@ pmg_status pmg_pc_mcgibbs_set_sweep_type(pmg_pc pc, int type);
 pmg_status pmg_pc_parsor_set_omega(pmg_pc pc, double omega);
 pmg_status pmg_pc_parsor_set_iterations(pmg_pc pc, int32_t its);
 pmg_status pmg_pc_parsor_apply_sor(pmg_pc pc, const double *b_dev, int32_t its, int zero_initial_guess, double *x_dev, void *stream);
+/* PCPARSOR's result depends on the number of MPI ranks: every rank sweeps its rows in the order TOP, INT1, MID, INT2,
+   BOT and reads old or new off-rank values depending on the ranks' colours (ParallelSORApply, src/pc_parsor.c:703-878;
+   ParallelSORPartitionNodes :272-592; ColorProcessors :187-270).  set_partition makes this PC reproduce the sweep of
+   `nparts` ranks owning the contiguous row blocks [row_starts[p], row_starts[p+1]) on one device (rows become the
+   nodes of a data-flow graph whose levels are swept as colours); proc_colors = the ranks' colours or NULL for first
+   fit in rank order (the reference's JP colouring is randomised and unpinned).  nparts = 0: single-rank order.
+   get_partition_info (after set-up): number of levels, rank colours, row classes (0 INT, 1 TOP, 2 MID, 3 BOT). */
+pmg_status pmg_pc_parsor_set_partition(pmg_pc pc, int32_t nparts, const int32_t *row_starts_host, const int32_t *proc_colors_host);
+pmg_status pmg_pc_parsor_get_partition_info(pmg_pc pc, int32_t *nlevels, int32_t *proc_colors_host, int32_t *node_classes_host);
 /* PCWOODBURY (src/woodbury.c): sampler for a MATLRC operator A + B S B^T built from any sampler of A plus a solver
    (a PC with `apply`) of A: set-up forms G = C (S^-1 + B^T C)^-1 with C = solver(B) (:21-91) and drops the solver;
    every sample adds B (sqrt(S) o eta) to the rhs, draws one sample of the inner sampler and applies y -= G (B^T y)

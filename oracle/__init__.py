@@ -14,7 +14,8 @@ reference's own known-answer tests -- ``examples/ex5.c`` (symmetric == forward t
 ``examples/ex1.c`` (sample mean -> A^-1 b), ``examples/ex6.c`` + ``src/stats.c`` (covariance metric) --
 see ``tests/test_oracle_*.py``.  What PETSc computes internally (JP colouring, GAMG aggregates,
 PetscRandom/MKL streams, the entries of DMDA interpolation) is "parity unpinned" by any reference
-fixture; those pieces follow PETSc's documentation and our own stated rules.
+fixture; those pieces follow PETSc's documentation and our own stated rules.  ``parsor.py`` is the literal
+multi-rank emulation of PCPARSOR's schedule (src/pc_parsor.c:703-878), pinned by properties only.
 """
 from __future__ import annotations
 

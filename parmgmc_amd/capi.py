@@ -190,6 +190,8 @@ _sig = {
     "pmg_pc_parsor_set_omega": (_int, [_vp, _dbl]),
     "pmg_pc_parsor_set_iterations": (_int, [_vp, _i32]),
     "pmg_pc_parsor_apply_sor": (_int, [_vp, _vp, _i32, _int, _vp, _vp]),
+    "pmg_pc_parsor_set_partition": (_int, [_vp, _i32, _vp, _vp]),
+    "pmg_pc_parsor_get_partition_info": (_int, [_vp, _vp, _vp, _vp]),
     "pmg_pc_gamgmc_set_levels": (_int, [_vp, _i32]),
     "pmg_pc_shell_set_apply": (_int, [_vp, _vp]),
     "pmg_pc_shell_set_context": (_int, [_vp, _vp]),

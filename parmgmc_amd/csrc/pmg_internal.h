@@ -56,6 +56,9 @@ pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream); /* after the sweep that us
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream);
 void       pmg_lrc_destroy(pmg_lrc *l);
+pmg_status pmg_mcsor_set_idiag_by_division(pmg_mcsor mc, int on); /* PCPARSOR's idiag = omega / d */
+/* pmg_parsor.c: data-flow form of PCPARSOR's multi-rank sweep; the four arrays are malloc'ed, the caller frees them */
+pmg_status pmg_parsor_build_dataflow(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int32_t nparts, const int32_t *row_starts, const int32_t *proccols_in, int32_t **e_rowptr, int32_t **e_colidx, double **e_vals, int32_t **e_colors, int32_t *nlevels_out, int32_t *proccols_out, int32_t *classes_out);
 int        pmg_invert_small(int k, double *a_colmajor, double *inv); /* Gauss-Jordan, partial pivoting; a is overwritten; nonzero = singular */
 
 /* device allocation helpers (zero-filled) */

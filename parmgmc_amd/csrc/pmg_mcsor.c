@@ -18,6 +18,7 @@ struct pmg_mcsor_s {
   /* options */
   double   omega;
   int      omega_changed;
+  int      idiag_by_division; /* PCPARSOR's rule: omega / d in one rounding (src/pc_parsor.c:69-81) instead of (1/d) * omega */
   int      type;
   int      rule;
   int32_t *user_colors; /* owned copy */
@@ -173,7 +174,7 @@ static pmg_status mcsor_update_idiag(pmg_mcsor mc)
       continue;
     }
     const double t = 1.0 / mc->diag_host[r];
-    id[r]          = t * mc->omega;
+    id[r]          = mc->idiag_by_division ? mc->omega / mc->diag_host[r] : t * mc->omega;
     sd[r]          = sqrt(fabs(mc->diag_host[r]));
     ss[r]          = sd[r] * s;
   }
@@ -318,6 +319,15 @@ pmg_status pmg_mcsor_setup(pmg_mcsor mc)
   /* the borrowed CSR is no longer needed */
   mc->rowptr = mc->colidx = NULL;
   mc->vals            = NULL;
+  return PMG_SUCCESS;
+}
+
+/* internal: LocalMatInvertDiagonalForSOR's idiag = omega / d (1 / d for omega = 1; src/pc_parsor.c:69-81) */
+pmg_status pmg_mcsor_set_idiag_by_division(pmg_mcsor mc, int on)
+{
+  PMG_CHECK(mc, PMG_ERR_ARG_NULL, "null MCSOR");
+  mc->idiag_by_division = on;
+  mc->omega_changed     = 1;
   return PMG_SUCCESS;
 }
 

@@ -545,6 +545,10 @@ typedef struct {
   int       its;
   pmg_mcsor mc;
   pmg_grid  g;
+  /* the sweep of `nparts` MPI ranks owning contiguous row blocks, reproduced on this device (pmg_parsor.c) */
+  int32_t  nparts, nlevels, *row_starts, *proccols_user, *proccols, *classes;
+  int32_t  ld;                     /* layout length of the 2n-row operator */
+  double  *xe, *be, *lay_b, *lay_y; /* [x; snapshot], [b; 0] in natural order and in the sweep layout */
 } pc_parsor;
 
 static pmg_status parsor_reset(pmg_pc pc)
@@ -552,12 +556,18 @@ static pmg_status parsor_reset(pmg_pc pc)
   pc_parsor *d = (pc_parsor *)pc->data;
   pmg_mcsor_destroy(&d->mc);
   pmg_grid_destroy(&d->g);
+  pmg_dev_free(d->xe), pmg_dev_free(d->be), pmg_dev_free(d->lay_b), pmg_dev_free(d->lay_y);
+  d->xe = d->be = d->lay_b = d->lay_y = NULL;
+  free(d->proccols), free(d->classes);
+  d->proccols = d->classes = NULL;
   return PMG_SUCCESS;
 }
 static pmg_status parsor_destroy(pmg_pc pc)
 {
   if (pc->data) {
+    pc_parsor *d = (pc_parsor *)pc->data;
     parsor_reset(pc);
+    free(d->row_starts), free(d->proccols_user);
     free(pc->data);
     pc->data = NULL;
   }
@@ -568,13 +578,36 @@ static pmg_status parsor_setup(pmg_pc pc)
   pc_parsor *d = (pc_parsor *)pc->data;
   parsor_reset(pc);
   PMG_CHECK(!pc->pmat->lrc_k, PMG_ERR_SUP, "parsor works on assembled matrices (MATAIJ), not MATLRC");
-  if (pc->pmat->kind == 1) { /* red-black order on the grid: a different but equally valid sweep order */
+  if (d->nparts > 0) { /* the order nparts ranks would sweep in (src/pc_parsor.c:703-878) */
+    const int32_t n = pc->pmat->n;
+    PMG_CHECK(pc->pmat->kind == 0, PMG_ERR_SUP, "a rank partition needs an assembled matrix (MATAIJ)");
+    PMG_CHECK(d->row_starts[d->nparts] == n, PMG_ERR_ARG_WRONG, "the partition covers %d rows, the matrix has %d", d->row_starts[d->nparts], n);
+    int32_t *rp = NULL, *ci = NULL, *cols = NULL;
+    double  *va = NULL;
+    d->proccols = (int32_t *)malloc(sizeof(int32_t) * (size_t)d->nparts);
+    d->classes  = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    PMG_CHECK(d->proccols && d->classes, PMG_ERR_MEM, "out of host memory");
+    PMG_CALL(pmg_parsor_build_dataflow(n, pc->pmat->rowptr, pc->pmat->colidx, pc->pmat->vals, d->nparts, d->row_starts, d->proccols_user, &rp, &ci, &va, &cols, &d->nlevels, d->proccols, d->classes));
+    pmg_status st = pmg_mcsor_create_csr(2 * n, rp, ci, va, &d->mc);
+    if (!st) st = pmg_mcsor_set_coloring(d->mc, PMG_COLORING_USER, cols);
+    if (!st) st = pmg_mcsor_set_omega(d->mc, d->omega);
+    if (!st) st = pmg_mcsor_set_idiag_by_division(d->mc, 1);
+    if (!st) st = pmg_mcsor_setup(d->mc); /* copies what it needs */
+    free(rp), free(ci), free(va), free(cols);
+    PMG_CALL(st);
+    PMG_CALL(pmg_mcsor_layout_len(d->mc, &d->ld));
+    PMG_CALL(pmg_dev_alloc((void **)&d->xe, sizeof(double) * 2 * (size_t)n));
+    PMG_CALL(pmg_dev_alloc((void **)&d->be, sizeof(double) * 2 * (size_t)n));
+    PMG_CALL(pmg_dev_alloc((void **)&d->lay_b, sizeof(double) * (size_t)d->ld));
+    PMG_CALL(pmg_dev_alloc((void **)&d->lay_y, sizeof(double) * (size_t)d->ld));
+  } else if (pc->pmat->kind == 1) { /* red-black order on the grid: a different but equally valid sweep order */
     PMG_CALL(pmg_grid_create(pc->pmat->nx, pc->pmat->ny, pc->pmat->nz, 0, pc->pmat->nz, pc->pmat->kappa, &d->g));
     PMG_CALL(pmg_grid_set_omega(d->g, d->omega));
   } else { /* dependency levels == the lexicographic order PCPARSOR preserves (src/pc_parsor.c:703-878) */
     PMG_CALL(pmg_mcsor_create_csr(pc->pmat->n, pc->pmat->rowptr, pc->pmat->colidx, pc->pmat->vals, &d->mc));
     PMG_CALL(pmg_mcsor_set_coloring(d->mc, PMG_COLORING_LEXLEVELS, NULL));
     PMG_CALL(pmg_mcsor_set_omega(d->mc, d->omega));
+    PMG_CALL(pmg_mcsor_set_idiag_by_division(d->mc, 1));
     PMG_CALL(pmg_mcsor_setup(d->mc));
   }
   return PMG_SUCCESS;
@@ -586,6 +619,22 @@ pmg_status pmg_pc_parsor_apply_sor(pmg_pc pc, const double *b, int32_t its, int 
   PMG_CALL(pmg_pc_setup(pc));
   pc_parsor *d = (pc_parsor *)pc->data;
   if (zero_initial_guess) PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)pc->pmat->n, (hipStream_t)stream));
+  if (d->nparts > 0) {
+    const size_t   nb = sizeof(double) * (size_t)pc->pmat->n;
+    hipStream_t    s  = (hipStream_t)stream;
+    PMG_HIP(hipMemcpyAsync(d->be, b, nb, hipMemcpyDeviceToDevice, s));
+    PMG_HIP(hipMemsetAsync(d->be + pc->pmat->n, 0, nb, s));
+    PMG_CALL(pmg_mcsor_to_layout(d->mc, d->be, d->lay_b, stream));
+    for (int32_t it = 0; it < its; ++it) {
+      PMG_HIP(hipMemcpyAsync(d->xe, x, nb, hipMemcpyDeviceToDevice, s));
+      PMG_HIP(hipMemcpyAsync(d->xe + pc->pmat->n, x, nb, hipMemcpyDeviceToDevice, s)); /* values from before the iteration */
+      PMG_CALL(pmg_mcsor_to_layout(d->mc, d->xe, d->lay_y, stream));
+      for (int32_t c = 0; c < d->nlevels; ++c) PMG_CALL(pmg_mcsor_sweep_color_layout(d->mc, c, 0, 0, 0, 0, d->lay_b, d->lay_y, stream));
+      PMG_CALL(pmg_mcsor_from_layout(d->mc, d->lay_y, d->xe, stream));
+      PMG_HIP(hipMemcpyAsync(x, d->xe, nb, hipMemcpyDeviceToDevice, s));
+    }
+    return PMG_SUCCESS;
+  }
   for (int32_t it = 0; it < its; ++it) {
     if (d->g) PMG_CALL(pmg_grid_apply(d->g, b, x, stream));
     else PMG_CALL(pmg_mcsor_apply(d->mc, b, x, stream));
@@ -620,6 +669,43 @@ pmg_status pmg_pc_parsor_set_omega(pmg_pc pc, double omega)
   PMG_CHECK(pc && !strcmp(pc->type, "parsor"), PMG_ERR_ARG_WRONG, "not a parsor PC");
   ((pc_parsor *)pc->data)->omega = omega;
   pc->setupcalled                = 0;
+  return PMG_SUCCESS;
+}
+/* Reproduce the sweep of `nparts` MPI ranks owning the contiguous row blocks [row_starts[p], row_starts[p+1])
+   (ParallelSORApply, src/pc_parsor.c:703-878; see pmg_parsor.c).  proc_colors: the colouring of the ranks
+   (ColorProcessors, :187-270), NULL = first fit in rank order.  nparts = 0 returns to the single-rank order. */
+pmg_status pmg_pc_parsor_set_partition(pmg_pc pc, int32_t nparts, const int32_t *row_starts, const int32_t *proc_colors)
+{
+  PMG_CHECK(pc && !strcmp(pc->type, "parsor"), PMG_ERR_ARG_WRONG, "not a parsor PC");
+  PMG_CHECK(nparts >= 0 && (nparts == 0 || row_starts), PMG_ERR_ARG_WRONG, "bad partition");
+  pc_parsor *d = (pc_parsor *)pc->data;
+  free(d->row_starts), free(d->proccols_user);
+  d->row_starts = d->proccols_user = NULL;
+  d->nparts                        = nparts;
+  if (nparts > 0) {
+    d->row_starts = (int32_t *)malloc(sizeof(int32_t) * ((size_t)nparts + 1));
+    PMG_CHECK(d->row_starts, PMG_ERR_MEM, "out of host memory");
+    memcpy(d->row_starts, row_starts, sizeof(int32_t) * ((size_t)nparts + 1));
+    if (proc_colors) {
+      d->proccols_user = (int32_t *)malloc(sizeof(int32_t) * (size_t)nparts);
+      PMG_CHECK(d->proccols_user, PMG_ERR_MEM, "out of host memory");
+      memcpy(d->proccols_user, proc_colors, sizeof(int32_t) * (size_t)nparts);
+    }
+  }
+  pc->setupcalled = 0;
+  return PMG_SUCCESS;
+}
+/* after set-up: number of dependency levels (= launches per iteration), the rank colours used and the class of every
+   row (0 INT, 1 TOP, 2 MID, 3 BOT; src/pc_parsor.c:283-288); any output may be NULL */
+pmg_status pmg_pc_parsor_get_partition_info(pmg_pc pc, int32_t *nlevels, int32_t *proc_colors, int32_t *node_classes)
+{
+  PMG_CHECK(pc && !strcmp(pc->type, "parsor"), PMG_ERR_ARG_WRONG, "not a parsor PC");
+  PMG_CALL(pmg_pc_setup(pc));
+  pc_parsor *d = (pc_parsor *)pc->data;
+  PMG_CHECK(d->nparts > 0, PMG_ERR_ARG_WRONGSTATE, "no rank partition set");
+  if (nlevels) *nlevels = d->nlevels;
+  if (proc_colors) memcpy(proc_colors, d->proccols, sizeof(int32_t) * (size_t)d->nparts);
+  if (node_classes) memcpy(node_classes, d->classes, sizeof(int32_t) * (size_t)pc->pmat->n);
   return PMG_SUCCESS;
 }
 pmg_status pmg_pc_parsor_set_iterations(pmg_pc pc, int32_t its)

@@ -149,6 +149,32 @@ class PC:
         sampler._borrowed = True
         self._inner = getattr(self, "_inner", []) + [sampler]
 
+    # --- PCPARSOR (reference include/parmgmc/pc/pc_parsor.h) ---
+    def parsor_set_omega(self, omega: float):
+        check(lib.pmg_pc_parsor_set_omega(self._h, omega))
+
+    def parsor_set_iterations(self, its: int):
+        check(lib.pmg_pc_parsor_set_iterations(self._h, its))
+
+    def parsor_apply_sor(self, b, its: int, zero_initial_guess: bool, x):
+        """PCPARSORApplySOR (reference src/pc_parsor.c:892-904)"""
+        check(lib.pmg_pc_parsor_apply_sor(self._h, _ptr(b), its, int(zero_initial_guess), _ptr(x), _stream()))
+
+    def parsor_set_partition(self, row_starts, proc_colors=None):
+        """reproduce the sweep of len(row_starts)-1 MPI ranks owning contiguous row blocks (src/pc_parsor.c:703-878)"""
+        rs = np.ascontiguousarray(row_starts, np.int32)
+        nparts = max(len(rs) - 1, 0)  # an empty list returns to the single-rank order
+        pcs = None if proc_colors is None else np.ascontiguousarray(proc_colors, np.int32)
+        check(lib.pmg_pc_parsor_set_partition(self._h, nparts, rs.ctypes.data if nparts else None, None if pcs is None else pcs.ctypes.data))
+        self._parsor_nparts = nparts
+
+    def parsor_partition_info(self):
+        """(number of dependency levels, rank colours, row classes 0 INT / 1 TOP / 2 MID / 3 BOT); sets the PC up"""
+        nl = C.c_int32()
+        pcs, cls = np.zeros(self._parsor_nparts, np.int32), np.zeros(self._mat.size, np.int32)
+        check(lib.pmg_pc_parsor_get_partition_info(self._h, C.byref(nl), pcs.ctypes.data, cls.ctypes.data))
+        return nl.value, pcs, cls
+
     def reset(self):
         check(lib.pmg_pc_reset(self._h))
 
