@@ -115,9 +115,28 @@ __global__ void sum_rows_kernel(int nrows, int count, const double *__restrict__
   out[c] = s;
 }
 
+// zero fill at streaming rate: the runtime's fill kernel runs 256 workgroups whatever the size (136 MB: 182 us; this
+// one: one 16-byte store per thread, ~30 us)
+typedef double d2z __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void fill_zero_kernel(double *__restrict__ p, int64_t n2, int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n2) reinterpret_cast<d2z *>(p)[i] = d2z{0.0, 0.0};
+  if (i == 0 && (n & 1)) p[n - 1] = 0.0;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
+
+// p must be 16-byte aligned (device allocations are)
+extern "C" int pmgk_fill_zero(double *p, int64_t n, void *stream)
+{
+  if (n <= 0) return 0;
+  const int64_t n2 = n / 2, nb = (n2 + 255) / 256;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)(nb > 0 ? nb : 1)), dim3(256), 0, (hipStream_t)stream, p, n2, n);
+  return launch_status();
+}
 
 extern "C" int pmgk_sum_rows(int nrows, int count, const double *in, double *out, void *stream)
 {

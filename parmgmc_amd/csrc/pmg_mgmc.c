@@ -1260,7 +1260,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
   for (int l = 0; l <= top; ++l) ctr[l] = sample * MG_DRAWS_PER_SAMPLE;
   for (int l = top; l >= 1; --l) {
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
-    if (l < top || !top_has_guess) PMG_HIP(hipMemsetAsync(Lv->x, 0, sizeof(double) * (size_t)Lv->ld, (hipStream_t)stream));
+    if (l < top || !top_has_guess) PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
     else if (Lv->is_st27) {
@@ -1276,7 +1276,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     if (h->coarse_type == 0) {
       PMG_CALL(pmg_chol_sample(h->chol, C0->b + C0->off, C0->x + C0->off, 1, level_seed(seed, 0), ctr[0], stream));
     } else {
-      PMG_HIP(hipMemsetAsync(C0->x, 0, sizeof(double) * (size_t)C0->ld, (hipStream_t)stream));
+      PMG_KERNEL(pmgk_fill_zero(C0->x, C0->ld, stream));
       if (C0->is_st27) PMG_CALL(st27_sample(h, C0, h->coarse_its, level_seed(seed, 0), &ctr[0], stream));
       else PMG_CALL(pmg_mcsor_sample_layout(C0->mc, C0->b, C0->x, h->coarse_its, h->scaled, level_seed(seed, 0), ctr[0], &ctr[0], stream));
     }
