@@ -41,6 +41,25 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
   return Philox4{c0, c1, c2, c3};
 }
 
+// fp64 FMAs with one operand in a SCALAR register pair.  A VALU fp64 instruction takes no 64-bit literal, and left to
+// itself the compiler turns every Horner step fma(s, w, C) into two v_mov_b32 (C into the accumulator) + v_fmac_f64:
+// three vector instructions in a kernel that is bound by vector issue.  With the constant in SGPRs (two s_mov_b32 on
+// the scalar unit, which has slots to spare) the step is ONE v_fma_f64.  `c` MUST be a compile-time constant (a
+// wave-uniform value): the "s" constraint would silently broadcast lane 0's value otherwise.  Same operation, same
+// rounding as fma().
+__device__ __forceinline__ double fma_vvs(double a, double b, double c) // a * b + c
+{
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+  return r;
+}
+__device__ __forceinline__ double fma_vsv(double a, double c, double b) // a * c + b
+{
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c), "v"(b));
+  return r;
+}
+
 struct LogTabEntry {
   double invc, logc;
 };
@@ -77,7 +96,7 @@ __device__ __forceinline__ void u53_int(uint32_t lo, uint32_t hi, uint32_t &xlo,
 // s = -2 ln(X * 2^-53), X = xhi:xlo in [1, 2^53]
 __device__ __forceinline__ double minus2_log_u(uint32_t xlo, uint32_t xhi, const LogTabEntry *tab)
 {
-  const double d = fma((double)xhi, 4294967296.0, (double)xlo); // exact
+  const double d = fma_vsv((double)xhi, 4294967296.0, (double)xlo); // exact
   // d = 2^k' * z with z in [0.6875, 1.375): subtract the bit pattern of 0.6875 from the high word
   const uint32_t dh  = (uint32_t)__double2hiint(d);
   const uint32_t tmp = dh - 0x3fe60000u;
@@ -90,11 +109,11 @@ __device__ __forceinline__ double minus2_log_u(uint32_t xlo, uint32_t xhi, const
   // log1p(r) = r - w/2 + r w (1/3 - r/4 + w (1/5 - r/6 + w/7))
   const double A  = fma(r, -0.25, 1.0 / 3.0);
   const double B  = fma(r, -1.0 / 6.0, 0.2);
-  const double q  = fma(w, fma(w, 1.0 / 7.0, B), A);
+  const double q  = fma(w, fma_vsv(w, 1.0 / 7.0, B), A);
   const double lp = fma(r * w, q, fma(w, -0.5, r));
   const double kd = (double)(k - 53); // ln u = (k-53) ln2 + ln c + log1p(r)
-  const double hi = fma(kd, PMG_LN2_HI, e.logc);
-  const double ln = hi + fma(kd, PMG_LN2_LO, lp);
+  const double hi = fma_vsv(kd, PMG_LN2_HI, e.logc);
+  const double ln = hi + fma_vsv(kd, PMG_LN2_LO, lp);
   return -2.0 * ln;
 }
 
@@ -119,25 +138,25 @@ __device__ __forceinline__ void sincos_turns(uint32_t ylo, uint32_t yhi, double 
 {
   const uint32_t q  = (yhi + (1u << 18)) >> 19;        // nearest quarter turn, 0..4
   const int32_t  rh = (int32_t)(yhi - (q << 19));      // remainder Y - q 2^51 in [-2^50, 2^50], high word
-  const double   r  = fma((double)rh, 4294967296.0, (double)ylo) * 0x1.0p-53; // turns, |r| <= 1/8, exact
+  const double   r  = fma_vsv((double)rh, 4294967296.0, (double)ylo) * 0x1.0p-53; // turns, |r| <= 1/8, exact
   const double   w  = r * r;
   double s = PMG_SIN_C8, c = PMG_COS_C9;
-  s = fma(s, w, PMG_SIN_C7);
-  c = fma(c, w, PMG_COS_C8);
-  s = fma(s, w, PMG_SIN_C6);
-  c = fma(c, w, PMG_COS_C7);
-  s = fma(s, w, PMG_SIN_C5);
-  c = fma(c, w, PMG_COS_C6);
-  s = fma(s, w, PMG_SIN_C4);
-  c = fma(c, w, PMG_COS_C5);
-  s = fma(s, w, PMG_SIN_C3);
-  c = fma(c, w, PMG_COS_C4);
-  s = fma(s, w, PMG_SIN_C2);
-  c = fma(c, w, PMG_COS_C3);
-  s = fma(s, w, PMG_SIN_C1);
-  c = fma(c, w, PMG_COS_C2);
-  s = fma(s, w, PMG_SIN_C0);
-  c = fma(c, w, PMG_COS_C1);
+  s = fma_vvs(s, w, PMG_SIN_C7);
+  c = fma_vvs(c, w, PMG_COS_C8);
+  s = fma_vvs(s, w, PMG_SIN_C6);
+  c = fma_vvs(c, w, PMG_COS_C7);
+  s = fma_vvs(s, w, PMG_SIN_C5);
+  c = fma_vvs(c, w, PMG_COS_C6);
+  s = fma_vvs(s, w, PMG_SIN_C4);
+  c = fma_vvs(c, w, PMG_COS_C5);
+  s = fma_vvs(s, w, PMG_SIN_C3);
+  c = fma_vvs(c, w, PMG_COS_C4);
+  s = fma_vvs(s, w, PMG_SIN_C2);
+  c = fma_vvs(c, w, PMG_COS_C3);
+  s = fma_vvs(s, w, PMG_SIN_C1);
+  c = fma_vvs(c, w, PMG_COS_C2);
+  s = fma_vvs(s, w, PMG_SIN_C0);
+  c = fma_vvs(c, w, PMG_COS_C1);
   s = s * r;
   c = fma(c, w, 1.0);
   // rotate by q quarter turns: q odd swaps, sin negated for q = 2,3, cos negated for q = 1,2
