@@ -53,6 +53,24 @@ __device__ __forceinline__ double st27_neighbour_sum(const pmgk_st27 &S, int i, 
   return acc;
 }
 
+// update of one point (i, j, global plane k): shared by the one-colour kernel and the plane kernel below
+template <bool NOISY>
+__device__ __forceinline__ void st27_update_point(const pmgk_st27 &S, int i, int j, int k, const double *s_coef, const double *s_idiag, const double *s_sqrtd, const pmg::LogTabEntry *s_logtab, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, double *y)
+{
+  const int64_t row  = i + (int64_t)S.nx * (j + (int64_t)S.ny * k); // global natural index: the noise counter
+  const int64_t lrow = i + (int64_t)S.nx * (j + (int64_t)S.ny * (k - S.kz0 + 1));
+  const int     cls  = pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nzg);
+  const double *cf   = s_coef + 27 * cls;
+  double        sum  = b[lrow];
+  if (NOISY) {
+    double z0, z1;
+    pmg::normal_pair((uint32_t)((uint64_t)row >> 1), 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
+    sum = ((row & 1) ? z1 : z0) * s_sqrtd[cls] + sum;
+  }
+  sum = st27_neighbour_sum<false>(S, i, j, k, (int32_t)lrow, cf, y, sum); // CSR rows hold in-domain entries only
+  y[lrow] = one_minus_omega * y[lrow] + s_idiag[cls] * sum;
+}
+
 template <bool NOISY>
 __global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int px, int py, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, double *y)
 {
@@ -73,18 +91,37 @@ __global__ __launch_bounds__(256) void st27_color_sweep_kernel(pmgk_st27 S, int 
   const int jj   = flat / cx, ii = flat - jj * cx;
   const int i = 2 * ii + px, j = 2 * jj + py, k = 2 * (int)blockIdx.z + kfirst; // k: global plane
   if (j >= S.ny || k >= S.kz0 + S.nz) return;
-  const int64_t row  = i + (int64_t)S.nx * (j + (int64_t)S.ny * k); // global natural index: the noise counter
-  const int64_t lrow = i + (int64_t)S.nx * (j + (int64_t)S.ny * (k - S.kz0 + 1));
-  const int     cls  = pos_class(i, S.nx) + 3 * pos_class(j, S.ny) + 9 * pos_class(k, S.nzg);
-  const double *cf   = s_coef + 27 * cls;
-  double        sum  = b[lrow];
-  if (NOISY) {
-    double z0, z1;
-    pmg::normal_pair((uint32_t)((uint64_t)row >> 1), 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
-    sum = ((row & 1) ? z1 : z0) * s_sqrtd[cls] + sum;
+  st27_update_point<NOISY>(S, i, j, k, s_coef, s_idiag, s_sqrtd, s_logtab, one_minus_omega, key0, key1, sweep, b, y);
+}
+
+// The four colours of one phase (one z-parity) in ONE launch: a workgroup owns a whole plane and sweeps its four (px, py)
+// colours one after the other with a workgroup barrier in between.  That is legal because the 26 neighbours of a point
+// in the planes above and below have the OTHER z-parity and do not change during the phase: all dependencies between
+// the colours of a phase lie inside the plane.  Against four launches: the planes k-1, k, k+1 are fetched once instead
+// of four times, and the small levels pay one launch latency instead of four.  Same arithmetic per point.
+template <bool NOISY>
+__global__ __launch_bounds__(1024) void st27_phase_kernel(pmgk_st27 S, int backward, int phase, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, double *y)
+{
+  __shared__ double           s_coef[27 * 27], s_idiag[27], s_sqrtd[27];
+  __shared__ pmg::LogTabEntry s_logtab[NOISY ? PMG_LOGTAB_SIZE : 1];
+  const int                   tid = threadIdx.x;
+  if (tid < 27 * 27) s_coef[tid] = S.coef[tid];
+  if (tid < 27) {
+    s_idiag[tid] = S.idiag[tid];
+    s_sqrtd[tid] = S.sqrtdiag[tid];
   }
-  sum = st27_neighbour_sum<false>(S, i, j, k, (int32_t)lrow, cf, y, sum); // CSR rows hold in-domain entries only
-  y[lrow] = one_minus_omega * y[lrow] + s_idiag[cls] * sum;
+  if (NOISY) pmg::load_log_table(s_logtab);
+  __syncthreads();
+  const int k = kfirst + 2 * (int)blockIdx.x; // global plane; the grid has exactly the owned planes of this parity
+  for (int q = 4 * phase; q < 4 * phase + 4; ++q) {
+    const int col = backward ? 7 - q : q, px = col & 1, py = (col >> 1) & 1;
+    const int cx = (S.nx - px + 1) / 2, cy = (S.ny - py + 1) / 2;
+    for (int f = tid; f < cx * cy; f += 1024) {
+      const int jj = f / cx, ii = f - jj * cx;
+      st27_update_point<NOISY>(S, 2 * ii + px, 2 * jj + py, k, s_coef, s_idiag, s_sqrtd, s_logtab, one_minus_omega, key0, key1, sweep, b, y);
+    }
+    __syncthreads(); // the next colour reads what this one stored (same workgroup: one L1, no cache maintenance)
+  }
 }
 
 // r = b - A y; the diagonal term is added last, like sell_residual_kernel
@@ -224,6 +261,22 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 extern "C" int pmgk_st27_sweep_phase(const pmgk_st27 *S, int backward, int phase, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream)
 {
   const double om1 = 1. - omega;
+  // one workgroup per plane pays only while the launch latency of four kernels is what a phase costs: measured on
+  // MI355X, planes of 33 x 33 points gain (257^3 V-cycle 0.912 -> 0.893 ms), 65 x 65 break even, 129 x 129 and larger
+  // lose (one CU per plane is latency-bound: 1.05 ms)
+  static int plane_limit = -1;
+  if (plane_limit < 0) {
+    const char *e = getenv("PMG_ST27_PHASE_MAX_PLANE");
+    plane_limit   = e ? atoi(e) : 1100; /* points per plane up to which the plane kernel is used */
+  }
+  if ((int64_t)S->nx * S->ny <= plane_limit) {
+    const int pz = backward ? 1 - phase : phase;
+    const int kfirst = S->kz0 + ((pz - S->kz0) & 1), cz = (S->kz0 + S->nz - kfirst + 1) / 2;
+    if (cz <= 0) return 0;
+    if (noisy) hipLaunchKernelGGL((st27_phase_kernel<true>), dim3(cz), dim3(1024), 0, (hipStream_t)stream, *S, backward, phase, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
+    else hipLaunchKernelGGL((st27_phase_kernel<false>), dim3(cz), dim3(1024), 0, (hipStream_t)stream, *S, backward, phase, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y);
+    return launch_status();
+  }
   for (int q = 4 * phase; q < 4 * phase + 4; ++q) {
     const int col = backward ? 7 - q : q;
     const int px = col & 1, py = (col >> 1) & 1, pz = (col >> 2) & 1;
