@@ -10,8 +10,9 @@ import torch
 from parmgmc_amd import GridMCSOR
 
 
-def timeit(fn, reps):
-    fn()
+def timeit(fn, reps, warm=100):
+    for _ in range(warm):  # past the clock transient after idle (the first ~100 launches run up to 40 % slower)
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
