@@ -256,7 +256,11 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
     if (face_lo || face_hi) { // every block of a face plane reports; the last one tells the neighbours
       // the peer stores are system-scope write-through stores (st2_sys): waiting for their completion is all a
       // wavefront has to do -- a system-scope release FENCE here would also write the whole L2 back, once per
-      // wavefront, while the interior blocks are filling it (measured: 2.5x slower)
+      // wavefront, while the interior blocks are filling it (measured: 2.5x slower).  The wait must be EXPLICIT and
+      // per wavefront: a workgroup-scope fence + barrier only drains lgkmcnt on gfx950, so without this s_waitcnt
+      // three of the four wavefronts of a face block could still have plane stores in flight over xGMI when the
+      // block's reporting thread bumps the counter (checked on the ISA by tests/test_isa_halo_wait.py)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads(); // one report per block: thousands of wavefronts on one counter would queue up at the L2
       if (threadIdx.x == 0 && threadIdx.y == 0) {
