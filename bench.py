@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: Gaussian samples/sec of the red-black Gibbs sweep on a 512^3 DMDA (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process IS a rank; started plainly it
+spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself before touching a GPU and relays
+rank 0's JSON line and the exit code.  A hang anywhere ends with "hang": true in the line and a non-zero exit code.
 
 A "step" is ONE SAMPLE = one forward Gibbs sweep (= both colour passes, noise generated in-kernel) of the
 sorgibbs/mcgibbs sampler on the 7-point operator of MatAssembleShiftedLaplaceFD (reference src/problems.c:14-75,
@@ -272,19 +276,86 @@ def mgmc_dist_secondary(rank: int, world: int, transport, share: bool, n: int = 
     return res
 
 
+def spawn_ranks(n: int, argv: list) -> int:
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start N fresh ranks (one per GPU) as a child
+    `python -m torch.distributed.run` BEFORE this process imports torch or touches a GPU, pass their output through
+    (rank 0 prints the JSON line) and return the child's exit code.  A child that outlives the limit is killed with its
+    whole process group and reported as a hang (non-zero)."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    limit = float(os.environ.get("PMG_BENCH_SPAWN_TIMEOUT", "1500"))
+    child = subprocess.Popen(cmd, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": n, "hang": True, "error": f"ranks still running after {limit:.0f} s: killed"}), flush=True)
+        return 3
+    except KeyboardInterrupt:
+        os.killpg(child.pid, signal.SIGKILL)
+        raise
+
+
+METRIC = "Gaussian samples/sec on 512^3 3D DMDA (7-pt Laplacian precision, red-black Gibbs sweep = 1 sorgibbs sample)"
+
+
+class Watchdog:
+    """A collective or a device wait that never returns must not look like success: when the deadline passes, rank 0
+    prints what it has with "hang": true and EVERY rank leaves with exit code 3 (torchrun then reports failure)."""
+
+    def __init__(self, rank: int, world: int, steps: int, warmup: int):
+        self.rank, self.world, self.steps, self.warmup = rank, world, steps, warmup
+        self.out, self.stage, self.timer, self.printed = None, "start", None, threading.Event()
+
+    def arm(self, seconds: float, stage: str):
+        self.cancel()
+        self.stage = stage
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self):
+        if self.rank == 0 and not self.printed.is_set():
+            self.printed.set()
+            line = dict(self.out) if self.out else {"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": self.world, "steps": self.steps, "warmup": self.warmup}
+            line["hang"] = True
+            line["hang_stage"] = self.stage
+            print(json.dumps(line), flush=True)
+        os._exit(3)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=100, help="untimed steps; the first ~50 steps after idle run up to 40 %% slower while the clocks settle")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps (a clock-settle phase of its own follows them, see settle())")
     ap.add_argument("--grid-n", dest="n", type=int, default=512, help="grid points per direction (default: the BASELINE 512^3)")
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--no-mgmc", action="store_true", help="skip the secondary V-cycle lines")
+    ap.add_argument("--no-settle", action="store_true", help="skip the clock-settle phase")
     ap.add_argument("--mgmc-n", type=int, default=513, help="grid of the distributed V-cycle line (2^k + 1)")
     ap.add_argument("--mgmc-levels", type=int, default=6)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -292,13 +363,17 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # rehearsal on a one-GPU box: PMG_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and bootstraps over gloo (RCCL
     # cannot run two ranks on one device); the sweep kernels, the schedule and the "ipc" halo transport are the real ones
     share = os.environ.get("PMG_BENCH_SHARE_DEVICE") == "1"
     if share:
         local = 0
+    dog = Watchdog(rank, world, args.steps, args.warmup)
+    dog.arm(float(os.environ.get("PMG_BENCH_HEADLINE_TIMEOUT", "420")), "headline")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -306,6 +381,7 @@ def main() -> None:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    cdev = "cpu" if (share or world == 1) else "cuda"  # where the small agreement tensors live
 
     from parmgmc_amd.dist import DistGridSampler
 
@@ -317,46 +393,96 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def agree(ok: bool) -> bool:
+        """True iff `ok` on every rank.  Every rank reaches every collective of measure() whatever failed locally:
+        local errors are carried in flags, never raised between two collectives"""
+        flag = torch.tensor([1 if ok else 0], device=cdev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def settle(smp, b, y, ctr):
+        """Clock-settle phase, independent of --warmup: after idle the first launches run fast, the next few dozen up to
+        40 % slower, then the clocks settle.  Untimed groups of 5 sweeps (10 colour launches) with an event between
+        groups run until three consecutive group means agree within 2 %; capped at 3 rounds of 32 groups (~0.3 s at
+        512^3 on one GPU).  All ranks take the decision together (the sample loop is collective over the halos)."""
+        groups, per, launches, hist = 32, 5, 0, []
+        for _round in range(3):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
+            evs[0].record()
+            for g_ in range(groups):
+                ctr = smp.sample_cvec(b, y, per, seed, ctr)
+                evs[g_ + 1].record()
+            torch.cuda.synchronize()
+            ms = [evs[i].elapsed_time(evs[i + 1]) / per for i in range(groups)]
+            hist += ms
+            launches += 2 * per * groups
+            last = ms[-3:]
+            ok = max(last) <= 1.02 * min(last)
+            if agree(ok):
+                break
+        hs = sorted(hist[-groups:])
+        return ctr, {"settle_launches": launches, "settle_ms_per_step_first": hist[0], "settle_ms_per_step_worst": max(hist), "settle_ms_per_step_last": hist[-1], "settle_ms_per_step_median_last_round": hs[len(hs) // 2]}
+
     def measure(transport):
-        """warm-up + timed region on one halo transport; returns everything the JSON line needs"""
-        smp = DistGridSampler(n, n, n, 10.0, rank, world, omega=args.omega, transport=transport)
+        """warm-up + settle + timed region on one halo transport; returns everything the JSON line needs.  Never raises
+        between collectives: a local failure is recorded and agreed on at the end"""
+        err = None
+        smp = DistGridSampler(n, n, n, 10.0, rank, world, omega=args.omega, transport=transport)  # agrees on its transport itself
         g = smp.grid
         nat_b = torch.ones(g.n, dtype=torch.float64, device="cuda")
         b = g.to_cvec(nat_b)
         del nat_b
         y = g.new_cvec()  # x0 = 0
-        ctr = smp.sample_cvec(b, y, args.warmup, seed, 0)
+        ctr, st = 0, {}
+        try:
+            ctr = smp.sample_cvec(b, y, args.warmup, seed, 0)
+            if not args.no_settle:
+                ctr, st = settle(smp, b, y, ctr)
+        except Exception as e:  # noqa: BLE001
+            err = f"warm-up: {type(e).__name__}: {e}"
+        if not agree(err is None):  # nobody enters the timed region unless everybody can
+            return dict(smp=smp, err=err or "warm-up failed on another rank", ok=False)
+        timed_from = ctr
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        ctr = smp.sample_cvec(b, y, args.steps, seed, ctr)
+        try:
+            ctr = smp.sample_cvec(b, y, args.steps, seed, ctr)
+        except Exception as e:  # noqa: BLE001
+            err = f"timed region: {type(e).__name__}: {e}"
         ev1.record()
         barrier()
         dt = time.perf_counter() - t0
-        smp.check()  # a device-side wait for a halo flag that gave up raises here
         dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream is the one passed to the C-ABI)
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+        try:
+            smp.check()  # a device-side wait for a halo flag that gave up shows here
+        except Exception as e:  # noqa: BLE001
+            err = err or f"{type(e).__name__}: {e}"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         finite = bool(torch.isfinite(y).all().item())
         # multi-GPU only, outside the timed region: rank 0 repeats the whole chain on ITS device alone and compares its
         # slab bit for bit (the noise depends on global indices only, so the distributed chain must reproduce it exactly)
         halo_check = None
-        if world > 1 and rank == 0 and os.environ.get("PMG_BENCH_NO_HALO_CHECK") != "1":
+        if err is None and world > 1 and rank == 0 and os.environ.get("PMG_BENCH_NO_HALO_CHECK") != "1":
             from parmgmc_amd import GridMCSOR
 
             one = GridMCSOR(n, n, n, 10.0)
             one.set_omega(args.omega)
             ob = one.to_cvec(torch.ones(one.n, dtype=torch.float64, device="cuda"))
             oy = one.new_cvec()
-            one.sample_cvec(ob, oy, args.warmup + args.steps, seed, 0, True)
+            one.sample_cvec(ob, oy, ctr, seed, 0, True)
             mine = g.from_cvec(y)
             ref = one.from_cvec(oy)[: mine.numel()]
             halo_check = "bit-identical to the single-device chain (rank 0's slab)" if torch.equal(mine, ref) else f"MISMATCH vs the single-device chain: max abs diff {float((mine - ref).abs().max()):.3e}"
             del one, ob, oy, mine, ref
             torch.cuda.empty_cache()
-        return dict(smp=smp, g=g, y=y, b=b, dt=float(tmax.item()), dev_ms=dev_ms, finite=finite, halo_check=halo_check)
+        good = err is None and (halo_check is None or halo_check.startswith("bit-identical"))
+        ok = agree(good)
+        return dict(smp=smp, g=g, y=y, b=b, dt=float(tmax.item()), dev_ms=dev_ms, finite=finite, halo_check=halo_check, settle=st, err=err, ok=ok, chain_len=ctr, timed_from=timed_from)
 
     # N > 1: the transports in order of preference; one that fails at run time (lost flag, wrong halo data) is dropped
     # and the next one measured -- decided by rank 0's bit-for-bit check, agreed by all ranks
@@ -364,23 +490,18 @@ def main() -> None:
     order = [forced] if (forced or world == 1) else ["ipc", "rccl", "torch"]
     res, tried = None, []
     for tr in order:
-        err = None
-        try:
-            res = measure(tr)
-        except Exception as e:  # noqa: BLE001
-            res, err = None, f"{type(e).__name__}: {e}"
-        good = res is not None and (res["halo_check"] is None or res["halo_check"].startswith("bit-identical"))
-        flag = torch.tensor([1 if good else 0], device="cpu" if (share or world == 1) else "cuda")
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        tried.append({"transport": tr, "actual": res["smp"].transport if res else None, "ok": bool(flag.item()), "error": err, "halo_check": res["halo_check"] if res else None})
-        if int(flag.item()) == 1:
+        res = measure(tr)
+        tried.append({"transport": tr, "actual": res["smp"].transport, "ok": res["ok"], "error": res["err"], "halo_check": res.get("halo_check")})
+        if res["ok"]:
             break
         if rank == 0:
-            print(f"[bench] halo transport {tr!r} rejected: {err or (res and res['halo_check'])}", file=sys.stderr, flush=True)
+            print(f"[bench] halo transport {tr!r} rejected: {res['err'] or res.get('halo_check') or 'failed on another rank'}", file=sys.stderr, flush=True)
         res = None
         torch.cuda.empty_cache()
-    assert res is not None, f"no halo transport produced a valid chain: {tried}"
+    if res is None:
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "error": "no halo transport produced a valid chain", "transports_tried": tried}), flush=True)
+        sys.exit(4)
     smp, g, y, b, dt, dev_ms, finite, halo_check = (res[k] for k in ("smp", "g", "y", "b", "dt", "dev_ms", "finite", "halo_check"))
     used_transport = smp.transport
 
@@ -393,7 +514,7 @@ def main() -> None:
         achieved = alg_bytes_per_launch / t_launch / 1e9
         traffic = measured_traffic(n) if (world == 1 and args.omega == 1.0) else None
         out = {
-            "metric": "Gaussian samples/sec on 512^3 3D DMDA (7-pt Laplacian precision, red-black Gibbs sweep = 1 sorgibbs sample)",
+            "metric": METRIC,
             "value": args.steps / dt,
             "unit": "samples/s",
             "n_gpus": world,
@@ -405,37 +526,28 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{n}^3 DMDA, 7-point shifted Laplacian (kappa=10, h2=1/(n-1)^2), b=1, x0=0, omega={args.omega:g}, forward red-black Gibbs sweep with in-kernel Philox4x32-10 + Box-Muller noise", "unknowns": N_total, "decomposition": f"{world} z-slab(s)", "halo": "none" if world == 1 else {"ipc": "1 plane/colour/neighbour, stored by the face kernel straight into the neighbour's receive block over xGMI (hipIpc peer memory), announced by a flag word the neighbour's face stream waits for; face stream runs beside the interior sweep", "rccl": "1 plane/colour/neighbour over RCCL ncclSend/ncclRecv", "torch": "1 plane/colour/neighbour over torch.distributed P2P (RCCL)"}[smp.transport], "transport": smp.transport},
+            "config": {"workload": f"{n}^3 DMDA, 7-point shifted Laplacian (kappa=10, h2=1/(n-1)^2), b=1, x0=0, omega={args.omega:g}, forward red-black Gibbs sweep with in-kernel Philox4x32-10 + Box-Muller noise", "unknowns": N_total, "decomposition": f"{world} z-slab(s)", "halo": "none" if world == 1 else {"ipc": "1 plane/colour/neighbour, stored by the face blocks of the sweep kernel straight into the neighbour's receive block over xGMI (hipIpc peer memory), announced by a flag word the neighbour's face wavefronts wait for inside the same launch", "rccl": "1 plane/colour/neighbour over RCCL ncclSend/ncclRecv", "torch": "1 plane/colour/neighbour over torch.distributed P2P (RCCL)"}[smp.transport], "transport": smp.transport},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None, "kernel": "grid_color_sweep_kernel", "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_us": t_launch * 1e6, "note": "24 B/unknown/sweep (read y, write y, read b once; SURVEY 8(d)) x N/2 unknowns per colour launch; duration = HIP-event time of the timed region / launches"},
             "finite": finite,
+            "clock_settle": res["settle"],
         }
         if halo_check is not None:
             out["halo_check"] = halo_check
         if len(tried) > 1:
             out["transports_tried"] = tried
+        dog.out = out
     else:
         out = None
     # ---- secondary lines: never allowed to cost the headline line -------------------------------------------------
-    printed = threading.Event()
-
     def emit():
-        if rank == 0 and not printed.is_set():
-            printed.set()
+        if rank == 0 and not dog.printed.is_set():
+            dog.printed.set()
             print(json.dumps(out), flush=True)
 
     if not args.no_mgmc and os.environ.get("PMG_BENCH_NO_MGMC") != "1":
         del b, y, smp, g, res
         torch.cuda.empty_cache()
-
-        def bail():  # a collective that never completes must not swallow the measured headline
-            if rank == 0:
-                out["secondary_mgmc_dist"] = {"error": "timed out after 240 s; headline unaffected"}
-                emit()
-            os._exit(0)
-
-        dog = threading.Timer(240.0, bail)
-        dog.daemon = True
-        dog.start()
+        dog.arm(float(os.environ.get("PMG_BENCH_SECONDARY_TIMEOUT", "300")), "secondary lines")  # a hang here: headline printed with "hang": true, exit code 3
         try:
             if world == 1:
                 out["secondary_mgmc"] = mgmc_secondary()
@@ -456,12 +568,14 @@ def main() -> None:
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 out["secondary_mgmc_dist"] = {"error": f"{type(e).__name__}: {e}"}
-        dog.cancel()
+    dog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, n)
     emit()
     if world > 1:
+        dog.arm(60.0, "destroy_process_group")
         dist.destroy_process_group()
+        dog.cancel()
 
 
 if __name__ == "__main__":

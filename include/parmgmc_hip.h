@@ -302,6 +302,18 @@ pmg_status pmg_mgmc_get_level_matrix(pmg_mgmc mg, int32_t level, int which, int3
    y = MG(b) when guesszero != 0), natural-order device vectors.  Sample s = counter0 + it draws its noise from
    counters [64 s, 64 s + 64) of per-level streams, so a chain can be resumed at any sample. */
 pmg_status pmg_mgmc_sample(pmg_mgmc mg, const double *b_nat_dev, double *y_nat_dev, int32_t its, int guesszero, uint64_t seed, uint64_t counter0, uint64_t *counter_out, pmg_sample_callback cb, void *cbctx, void *stream);
+/* Diagnostics: ONE kernel of the V-cycle on caller-supplied device vectors in the level's own layout (single device).
+   They exist for the parity tests at 257^3 / 513^3, where a whole oracle cycle is out of reach: the tests run one
+   kernel and compare sampled rows with the oracle's row arithmetic (PCMG pieces entered at reference
+   src/pc_gamgmc.c:246,255; level sweeps = MCSORApply_SEQAIJ, src/mc_sor.c:241-296).
+   layout kinds: 0 = grid level (colour-partitioned cvec), 1 = class-stencil level and 3 = dense coarsest level (natural
+   order behind one ghost plane: natural index q at off + q), 2 = sliced-ELL level (pmg_mcsor layout). */
+pmg_status pmg_mgmc_get_level_layout(pmg_mgmc mg, int32_t level, int32_t *kind, int64_t *ld, int64_t *off);
+pmg_status pmg_mgmc_get_level_stencil(pmg_mgmc mg, int32_t level, double *coef_27x27_host, double *sqrtdiag_27_host);
+pmg_status pmg_mgmc_level_sweep(pmg_mgmc mg, int32_t level, int backward, int noisy, uint64_t seed, uint64_t counter, const double *b_lvl, double *x_lvl, void *stream);
+pmg_status pmg_mgmc_level_residual(pmg_mgmc mg, int32_t level, const double *b_lvl, const double *x_lvl, double *r_lvl, void *stream);
+pmg_status pmg_mgmc_level_restrict(pmg_mgmc mg, int32_t level, double *r_fine_lvl, double *b_coarse_lvl, void *stream);
+pmg_status pmg_mgmc_level_prolong_add(pmg_mgmc mg, int32_t level, const double *e_coarse_lvl, double *x_fine_lvl, void *stream);
 pmg_status pmg_mgmc_destroy(pmg_mgmc *mg);
 
 /* ------------------------------------------------------------------------------------------------------ */

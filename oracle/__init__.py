@@ -95,6 +95,13 @@ def _declare(L: C.CDLL) -> None:
     L.orc_potrf_lower.argtypes = [C.c_int, _f64p]
     L.orc_chol_sample.argtypes = [C.c_int, _f64p, _f64p, _f64p, _f64p]
     L.orc_spmv.argtypes = [C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p]
+    _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+    L.orc_grid7_rows_sweep.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, _i64p, _f64p, _f64p, _f64p, _f64p]
+    L.orc_grid7_rows_residual.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int64, _i64p, _f64p, _f64p, _f64p]
+    L.orc_st27_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, _i64p, _f64p, _f64p, _f64p, _f64p]
+    L.orc_q1_rows.argtypes = [C.c_int, _i32p, _i32p, C.c_int64, _i64p, _f64p, _f64p, _f64p]
+    for f in (L.orc_grid7_rows_sweep, L.orc_grid7_rows_residual, L.orc_st27_rows, L.orc_q1_rows):
+        f.restype = None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -586,3 +593,81 @@ def covariance_errors(A: CSR, samples: np.ndarray, chains: int) -> np.ndarray:
         W = S - S.mean(0)
         out[i] = np.linalg.norm(W.T @ W / (chains - 1) - Q) / np.linalg.norm(Q)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# sampled-row restatements (full-size parity: 256^3 ... 513^3, where a whole CPU sweep takes too long)
+# ------------------------------------------------------------------------------------------------
+def _rows64(rows) -> np.ndarray:
+    return np.ascontiguousarray(rows, np.int64)
+
+
+def grid7_rows_sweep(nx, ny, nz, kappa, rows, b, y0, y1, omega=1.0, backward=False, noisy=False, scaled=True, seed=0, sweep=0) -> np.ndarray:
+    """Values the reference loop (src/mc_sor.c:256-271, red-black colouring) gives the sampled `rows` of the 7-point
+    grid operator in one directional sweep that took y0 to y1 (natural-order host vectors)."""
+    rows = _rows64(rows)
+    out = np.zeros(len(rows))
+    lib().orc_grid7_rows_sweep(nx, ny, nz, kappa, omega, int(backward), int(noisy), int(scaled), seed, sweep, len(rows), rows, np.ascontiguousarray(b), np.ascontiguousarray(y0), np.ascontiguousarray(y1), out)
+    return out
+
+
+def grid7_rows_residual(nx, ny, nz, kappa, rows, b, y) -> np.ndarray:
+    rows = _rows64(rows)
+    out = np.zeros(len(rows))
+    lib().orc_grid7_rows_residual(nx, ny, nz, kappa, len(rows), rows, np.ascontiguousarray(b), np.ascontiguousarray(y), out)
+    return out
+
+
+def st27_rows_sweep(nx, ny, nz, coef, sqrtd, rows, b, y0, y1, omega=1.0, backward=False, noisy=False, seed=0, sweep=0) -> np.ndarray:
+    """same for a 27-point class-stencil operator under the 8-colour parity colouring (coef: 27 x 27 class table)"""
+    rows = _rows64(rows)
+    out = np.zeros(len(rows))
+    lib().orc_st27_rows(0, nx, ny, nz, np.ascontiguousarray(coef, np.float64).ravel(), np.ascontiguousarray(sqrtd, np.float64), omega, int(backward), int(noisy), seed, sweep, len(rows), rows, np.ascontiguousarray(b), np.ascontiguousarray(y0), np.ascontiguousarray(y1), out)
+    return out
+
+
+def st27_rows_residual(nx, ny, nz, coef, rows, b, y) -> np.ndarray:
+    rows = _rows64(rows)
+    out = np.zeros(len(rows))
+    yy = np.ascontiguousarray(y)
+    lib().orc_st27_rows(1, nx, ny, nz, np.ascontiguousarray(coef, np.float64).ravel(), np.zeros(27), 1.0, 0, 0, 0, 0, len(rows), rows, np.ascontiguousarray(b), yy, yy, out)
+    return out
+
+
+def q1_rows_restrict(nf, nc, rows, r_fine) -> np.ndarray:
+    rows = _rows64(rows)
+    out = np.zeros(len(rows))
+    rf = np.ascontiguousarray(r_fine)
+    lib().orc_q1_rows(0, np.asarray(nf, np.int32), np.asarray(nc, np.int32), len(rows), rows, rf, rf, out)
+    return out
+
+
+def q1_rows_prolong_add(nf, nc, rows, x_fine, e_coarse) -> np.ndarray:
+    rows = _rows64(rows)
+    out = np.zeros(len(rows))
+    lib().orc_q1_rows(1, np.asarray(nf, np.int32), np.asarray(nc, np.int32), len(rows), rows, np.ascontiguousarray(x_fine), np.ascontiguousarray(e_coarse), out)
+    return out
+
+
+def st27_table_from_csr(nx, ny, nz, A: "CSR"):
+    """27 x 27 class table of a structured 27-point matrix (first point of each position class); also returns whether
+    EVERY row equals its class stencil bit for bit."""
+    coef = np.zeros((27, 27))
+    have = np.zeros(27, bool)
+    exact = True
+    cls_of = lambda i, n: 0 if i == 0 else (2 if i == n - 1 else 1)  # noqa: E731
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                row = i + nx * (j + ny * k)
+                cls = cls_of(i, nx) + 3 * cls_of(j, ny) + 9 * cls_of(k, nz)
+                loc = np.zeros(27)
+                for q in range(A.rowptr[row], A.rowptr[row + 1]):
+                    c = int(A.colidx[q])
+                    dx, dy, dz = c % nx - i, (c // nx) % ny - j, c // (nx * ny) - k
+                    loc[9 * (dz + 1) + 3 * (dy + 1) + dx + 1] = A.vals[q]
+                if not have[cls]:
+                    coef[cls], have[cls] = loc, True
+                elif not np.array_equal(coef[cls], loc):
+                    exact = False
+    return coef, have, exact

@@ -50,6 +50,33 @@ int64_t orc_laplace_nnz(int nx, int ny, int nz)
      - rows in DMDA natural order idx = i + nx*(j + ny*k); PETSc AIJ keeps the columns of a
        row sorted ascending whatever the insertion order, so the stored order is
        (k-1) (j-1) (i-1) diag (i+1) (j+1) (k+1). */
+/* one row of that matrix: columns (64-bit) and values in storage order, *dpos = position of the diagonal;
+   returns the number of entries (<= 7).  Shared by the assembly below and by the sampled-row checks further down,
+   so that the rows recomputed at 512^3 are the rows the pinned assembly produces. */
+static inline int orc_laplace_row(int nx, int ny, int nz, double kappa, double hinv2, int i, int j, int k, int64_t *cols, double *vals, int *dpos)
+{
+  const int64_t row  = i + (int64_t)nx * (j + (int64_t)ny * k);
+  double        diag = kappa * kappa;
+  int           p    = 0;
+  /* the reference adds in the order south, west, north, east; all addends are equal so
+     the sum is order independent -- only the COUNT of additions matters */
+  if (k > 0) diag += hinv2;
+  if (j > 0) diag += hinv2;
+  if (i > 0) diag += hinv2;
+  if (k < nz - 1) diag += hinv2;
+  if (j < ny - 1) diag += hinv2;
+  if (i < nx - 1) diag += hinv2;
+  if (k > 0) { cols[p] = row - (int64_t)nx * ny; vals[p++] = -hinv2; }
+  if (j > 0) { cols[p] = row - nx; vals[p++] = -hinv2; }
+  if (i > 0) { cols[p] = row - 1; vals[p++] = -hinv2; }
+  *dpos = p;
+  cols[p] = row; vals[p++] = diag;
+  if (i < nx - 1) { cols[p] = row + 1; vals[p++] = -hinv2; }
+  if (j < ny - 1) { cols[p] = row + nx; vals[p++] = -hinv2; }
+  if (k < nz - 1) { cols[p] = row + (int64_t)nx * ny; vals[p++] = -hinv2; }
+  return p;
+}
+
 void orc_assemble_shifted_laplace(int nx, int ny, int nz, double kappa, int32_t *rowptr, int32_t *colidx, double *vals)
 {
   const double hinv2 = 1. / ((nx - 1) * (nx - 1));
@@ -57,24 +84,13 @@ void orc_assemble_shifted_laplace(int nx, int ny, int nz, double kappa, int32_t 
   for (int k = 0; k < nz; k++)
     for (int j = 0; j < ny; j++)
       for (int i = 0; i < nx; i++) {
-        const int64_t row  = i + (int64_t)nx * (j + (int64_t)ny * k);
-        double        diag = kappa * kappa;
-        rowptr[row]        = (int32_t)p;
-        /* the reference adds in the order south, west, north, east; all addends are equal so
-           the sum is order independent -- only the COUNT of additions matters */
-        if (k > 0) diag += hinv2;
-        if (j > 0) diag += hinv2;
-        if (i > 0) diag += hinv2;
-        if (k < nz - 1) diag += hinv2;
-        if (j < ny - 1) diag += hinv2;
-        if (i < nx - 1) diag += hinv2;
-        if (k > 0) { colidx[p] = (int32_t)(row - (int64_t)nx * ny); vals[p++] = -hinv2; }
-        if (j > 0) { colidx[p] = (int32_t)(row - nx); vals[p++] = -hinv2; }
-        if (i > 0) { colidx[p] = (int32_t)(row - 1); vals[p++] = -hinv2; }
-        colidx[p] = (int32_t)row; vals[p++] = diag;
-        if (i < nx - 1) { colidx[p] = (int32_t)(row + 1); vals[p++] = -hinv2; }
-        if (j < ny - 1) { colidx[p] = (int32_t)(row + nx); vals[p++] = -hinv2; }
-        if (k < nz - 1) { colidx[p] = (int32_t)(row + (int64_t)nx * ny); vals[p++] = -hinv2; }
+        const int64_t row = i + (int64_t)nx * (j + (int64_t)ny * k);
+        int64_t       c[7];
+        double        v[7];
+        int           dpos;
+        const int     n = orc_laplace_row(nx, ny, nz, kappa, hinv2, i, j, k, c, v, &dpos);
+        rowptr[row]     = (int32_t)p;
+        for (int q = 0; q < n; ++q) { colidx[p] = (int32_t)c[q]; vals[p++] = v[q]; }
       }
   rowptr[(int64_t)nx * ny * nz] = (int32_t)p;
 }
@@ -319,21 +335,23 @@ void orc_noise_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi)
    colour-partitioned storage order the device uses.  Counter = {q, line = j + ny*k (global),
    sweep low, (sweep high & 0x7fffffff) | c<<31}.  The definition uses GLOBAL indices only, so
    the noise does not depend on how the grid is split over devices. */
+static inline double orc_noise_grid_point(int ny, int i, int j, int k, const uint32_t key[2], uint64_t sweep)
+{
+  const uint32_t line   = (uint32_t)(j + (int64_t)ny * k);
+  const int      c      = (i + j + k) & 1;
+  const int      m      = i >> 1;
+  const uint32_t ctr[4] = {(uint32_t)(m >> 1), line, (uint32_t)sweep, ((uint32_t)(sweep >> 32) & 0x7fffffffu) | ((uint32_t)c << 31)};
+  double         z[2];
+  orc_normal_pair(ctr, key, z);
+  return z[m & 1];
+}
+
 void orc_noise_grid(int nx, int ny, int nz, uint64_t seed, uint64_t sweep, double *xi)
 {
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
   for (int k = 0; k < nz; ++k)
-    for (int j = 0; j < ny; ++j) {
-      const uint32_t line = (uint32_t)(j + (int64_t)ny * k);
-      for (int i = 0; i < nx; ++i) {
-        const int      c      = (i + j + k) & 1;
-        const int      m      = i >> 1;
-        const uint32_t ctr[4] = {(uint32_t)(m >> 1), line, (uint32_t)sweep, ((uint32_t)(sweep >> 32) & 0x7fffffffu) | ((uint32_t)c << 31)};
-        double         z[2];
-        orc_normal_pair(ctr, key, z);
-        xi[i + (int64_t)nx * (j + (int64_t)ny * k)] = z[m & 1];
-      }
-    }
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) xi[i + (int64_t)nx * (j + (int64_t)ny * k)] = orc_noise_grid_point(ny, i, j, k, key, sweep);
 }
 
 /* PrepareRHS_Default, reference src/pc_mcgibbs.c:119-128 (and its twin in PCSORGibbsSample,
@@ -458,5 +476,171 @@ void orc_spmv(int nrows, const int32_t *rowptr, const int32_t *colidx, const dou
     double s = 0;
     for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) s += vals[k] * x[colidx[k]];
     y[r] = s;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Sampled-row restatements for parity checks at sizes where a whole sweep takes the CPU too long
+ * (256^3 ... 513^3): the SAME row arithmetic as above, for a list of rows only.
+ *
+ * A multicolour sweep visits colour after colour, so when row r of colour c is updated its
+ * neighbours of a lower colour already hold their new values and those of a higher colour
+ * still hold the old ones (forward order; reversed for a backward sweep).  Given the vector
+ * before (y0) and after (y1) the whole sweep, the value the reference loop computes for row r
+ * is therefore a function of y0, y1 and the colour rule alone.
+ * ---------------------------------------------------------------------------------------- */
+
+/* rows of the 7-point grid operator, red-black colouring c = (i+j+k)&1 (colour 0 first when forward).
+   Row update per reference src/mc_sor.c:261-267 (orc_row_update), right-hand side per
+   src/pc_mcgibbs.c:119-128 (orc_prepare_rhs) with the grid noise stream when noisy. */
+void orc_grid7_rows_sweep(int nx, int ny, int nz, double kappa, double omega, int backward, int noisy, int scaled, uint64_t seed, uint64_t sweep, int64_t nrows, const int64_t *rows, const double *b, const double *y0, const double *y1, double *out)
+{
+  const double   hinv2  = 1. / ((nx - 1) * (nx - 1));
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  const double   sc     = sqrt((2 - omega) / omega);
+  for (int64_t q = 0; q < nrows; ++q) {
+    const int64_t r = rows[q];
+    const int     i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((int64_t)nx * ny));
+    int64_t       c[7];
+    double        v[7];
+    int           dpos;
+    const int     n    = orc_laplace_row(nx, ny, nz, kappa, hinv2, i, j, k, c, v, &dpos);
+    const int     mine = (i + j + k) & 1;
+    /* neighbours have the other colour: new values iff that colour was swept before mine */
+    const int     nb_new = backward ? (mine == 0) : (mine == 1);
+    const double *yn     = nb_new ? y1 : y0;
+    const double  t      = 1.0 / v[dpos];
+    const double  idiag  = t * omega; /* orc_idiag */
+    double        w      = b[r];
+    if (noisy) {
+      const double sd0 = sqrt(fabs(v[dpos]));
+      const double sd  = scaled ? sd0 * sc : sd0; /* orc_sqrtdiag */
+      double       xi  = orc_noise_grid_point(ny, i, j, k, key, sweep);
+      xi               = xi * sd; /* orc_prepare_rhs: three passes */
+      w                = xi + b[r];
+    }
+    double sum = w;
+    for (int e = 0; e < dpos; ++e) sum -= v[e] * yn[c[e]];
+    for (int e = dpos + 1; e < n; ++e) sum -= v[e] * yn[c[e]];
+    out[q] = (1. - omega) * y0[r] + idiag * sum;
+  }
+}
+
+/* r = b - A y for sampled rows of the grid operator: MatMult row sum in storage order including the
+   diagonal at its place, then VecAYPX(w,-1,b) (reference src/pc_gamgmc.c:253-254; orc_spmv) */
+void orc_grid7_rows_residual(int nx, int ny, int nz, double kappa, int64_t nrows, const int64_t *rows, const double *b, const double *y, double *out)
+{
+  const double hinv2 = 1. / ((nx - 1) * (nx - 1));
+  for (int64_t q = 0; q < nrows; ++q) {
+    const int64_t r = rows[q];
+    const int     i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((int64_t)nx * ny));
+    int64_t       c[7];
+    double        v[7];
+    int           dpos;
+    const int     n = orc_laplace_row(nx, ny, nz, kappa, hinv2, i, j, k, c, v, &dpos);
+    double        s = 0.0;
+    for (int e = 0; e < n; ++e) s += v[e] * y[c[e]];
+    out[q] = b[r] - s;
+  }
+}
+
+/* Rows of a 27-point class-stencil operator (coef[27*cls + e], e = 9(dz+1)+3(dy+1)+(dx+1); the assembled row holds
+   the in-domain entries in ascending column order), 8 parity colours (i&1) + 2(j&1) + 4(k&1) swept ascending
+   (descending when backward), noise = row stream of the natural index (orc_noise_rows).  which = 0: sweep value as
+   in orc_grid7_rows_sweep (sqrtd[cls] is the noise scale); which = 1: residual b - A y0 with the diagonal added
+   LAST (the order of the library's sliced-ELL residual, which keeps the diagonal apart). */
+void orc_st27_rows(int which, int nx, int ny, int nz, const double *coef, const double *sqrtd, double omega, int backward, int noisy, uint64_t seed, uint64_t sweep, int64_t nrows, const int64_t *rows, const double *b, const double *y0, const double *y1, double *out)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (int64_t q = 0; q < nrows; ++q) {
+    const int64_t r = rows[q];
+    const int     i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((int64_t)nx * ny));
+    const int     cls = (i == 0 ? 0 : (i == nx - 1 ? 2 : 1)) + 3 * (j == 0 ? 0 : (j == ny - 1 ? 2 : 1)) + 9 * (k == 0 ? 0 : (k == nz - 1 ? 2 : 1));
+    const double *cf   = coef + 27 * cls;
+    const int     mine = (i & 1) + 2 * (j & 1) + 4 * (k & 1);
+    const double  d    = cf[13];
+    if (which == 1) {
+      double s = 0.0;
+      int    e = 0;
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx, ++e) {
+            if (e == 13 || i + dx < 0 || i + dx >= nx || j + dy < 0 || j + dy >= ny || k + dz < 0 || k + dz >= nz) continue;
+            s += cf[e] * y0[r + dx + (int64_t)nx * (dy + (int64_t)ny * dz)];
+          }
+      s += d * y0[r];
+      out[q] = b[r] - s;
+      continue;
+    }
+    double w = b[r];
+    if (noisy) {
+      const uint64_t pr     = (uint64_t)r >> 1;
+      const uint32_t ctr[4] = {(uint32_t)pr, (uint32_t)(pr >> 32), (uint32_t)sweep, (uint32_t)(sweep >> 32)};
+      double         z[2];
+      orc_normal_pair(ctr, key, z);
+      double xi = z[r & 1];
+      xi        = xi * sqrtd[cls];
+      w         = xi + b[r];
+    }
+    double sum = w;
+    int    e   = 0;
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx, ++e) {
+          if (e == 13 || i + dx < 0 || i + dx >= nx || j + dy < 0 || j + dy >= ny || k + dz < 0 || k + dz >= nz) continue;
+          const int     other = ((i + dx) & 1) + 2 * ((j + dy) & 1) + 4 * ((k + dz) & 1);
+          const int     isnew = backward ? other > mine : other < mine;
+          const int64_t cidx  = r + dx + (int64_t)nx * (dy + (int64_t)ny * dz);
+          sum -= cf[e] * (isnew ? y1[cidx] : y0[cidx]);
+        }
+    const double t = 1.0 / d;
+    out[q]         = (1. - omega) * y0[r] + (t * omega) * sum;
+  }
+}
+
+/* Q1 transfers of a DMDA hierarchy for sampled rows (PETSc DMCreateInterpolation semantics as restated by
+   q1_interp in oracle/__init__.py: fine 2I = coarse I, fine 2I+1 midway with weights 1/2, 1/2, tensor product).
+   restrict: out = (P^T r)[I] -- a CSR row of P^T, fine columns ascending, summed from 0;
+   prolong:  out = x[f] + (P e)[f] -- a CSR row of P, coarse columns ascending, summed from 0, then MatInterpolateAdd. */
+void orc_q1_rows(int which, const int32_t nf[3], const int32_t nc[3], int64_t nrows, const int64_t *rows, const double *fine, const double *coarse, double *out)
+{
+  for (int64_t q = 0; q < nrows; ++q) {
+    const int64_t r = rows[q];
+    if (which == 0) { /* coarse row I of P^T */
+      const int I[3] = {(int)(r % nc[0]), (int)((r / nc[0]) % nc[1]), (int)(r / ((int64_t)nc[0] * nc[1]))};
+      int       lo[3], hi[3];
+      for (int d = 0; d < 3; ++d) {
+        const int ref = nf[d] != nc[d];
+        const int f   = ref ? 2 * I[d] : I[d];
+        lo[d]         = ref ? (f - 1 < 0 ? 0 : f - 1) : f;
+        hi[d]         = ref ? (f + 1 > nf[d] - 1 ? nf[d] - 1 : f + 1) : f;
+      }
+      double s = 0.0;
+      for (int k = lo[2]; k <= hi[2]; ++k)
+        for (int j = lo[1]; j <= hi[1]; ++j)
+          for (int i = lo[0]; i <= hi[0]; ++i) {
+            const int    f[3] = {i, j, k};
+            double       w    = 1.0;
+            for (int d = 0; d < 3; ++d)
+              if (nf[d] != nc[d] && (f[d] & 1)) w *= 0.5;
+            s += w * fine[i + (int64_t)nf[0] * (j + (int64_t)nf[1] * k)];
+          }
+      out[q] = s;
+    } else { /* fine row f of P */
+      const int f[3] = {(int)(r % nf[0]), (int)((r / nf[0]) % nf[1]), (int)(r / ((int64_t)nf[0] * nf[1]))};
+      int       c0[3], m[3];
+      double    w = 1.0;
+      for (int d = 0; d < 3; ++d) {
+        const int ref = nf[d] != nc[d];
+        c0[d]         = ref ? f[d] / 2 : f[d];
+        m[d]          = (ref && (f[d] & 1)) ? 2 : 1;
+        if (m[d] == 2) w *= 0.5;
+      }
+      double s = 0.0;
+      for (int c = 0; c < m[2]; ++c)
+        for (int bq = 0; bq < m[1]; ++bq)
+          for (int a = 0; a < m[0]; ++a) s += w * coarse[(c0[0] + a) + (int64_t)nc[0] * ((c0[1] + bq) + (int64_t)nc[1] * (c0[2] + c))];
+      out[q] = fine[r] + s;
+    }
   }
 }

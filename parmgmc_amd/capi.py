@@ -152,6 +152,12 @@ _sig = {
     "pmg_mgmc_get_level_matrix": (_int, [_vp, _i32, _int, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _vp]),
     "pmg_mgmc_sample": (_int, [_vp, _vp, _vp, _i32, _int, _u64, _u64, C.POINTER(_u64), _vp, _vp, _vp]),
     "pmg_mgmc_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_mgmc_get_level_layout": (_int, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
+    "pmg_mgmc_get_level_stencil": (_int, [_vp, _i32, _vp, _vp]),
+    "pmg_mgmc_level_sweep": (_int, [_vp, _i32, _int, _int, _u64, _u64, _vp, _vp, _vp]),
+    "pmg_mgmc_level_residual": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "pmg_mgmc_level_restrict": (_int, [_vp, _i32, _vp, _vp, _vp]),
+    "pmg_mgmc_level_prolong_add": (_int, [_vp, _i32, _vp, _vp, _vp]),
     "pmg_initialize": (_int, []),
     "pmg_finalize": (_int, []),
     "pmg_pc_register": (_int, [C.c_char_p, _vp]),

@@ -1250,6 +1250,27 @@ static pmg_status mg_restrict(pmg_mgmc h, int l, double *r_fine, double *b_coars
   return PMG_SUCCESS;
 }
 
+/* x_fine += P_l e_coarse (MatInterpolateAdd).  only_color (grid level): -1 = both colours, else just that one. */
+static pmg_status mg_prolong_add(pmg_mgmc h, int l, const double *e_coarse, double *x_fine, int only_color, void *stream)
+{
+  mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
+  /* a z-slab also interpolates onto its in-domain ghost planes (from its coarse planes + coarse ghost planes): the
+     same arithmetic the owner does, so the fine ghost planes stay current without an exchange */
+  const int glo = Lv->distributed && Lv->kz0 > 0, ghi = Lv->distributed && Lv->kz0 + Lv->nzl < Lv->nz;
+  if (Lv->grid_transfer) { /* matrix-free */
+    pmgk_grid_layout     GL;
+    const pmgk_st27_dims CD = level_dims(Cc);
+    PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
+    PMG_KERNEL(pmgk_q1_prolong_add(&GL, &CD, Lv->cpos_dev, -glo, Lv->nzl + glo + ghi, only_color, e_coarse, x_fine, stream));
+  } else if (Lv->nat_transfer) {
+    const pmgk_st27_dims FD = level_dims(Lv), CD = level_dims(Cc);
+    PMG_KERNEL(pmgk_st27_prolong_add(&FD, &CD, Lv->kz0 - glo, Lv->nzl + glo + ghi, e_coarse, x_fine, stream));
+  } else {
+    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, e_coarse, x_fine, 1, stream));
+  }
+  return PMG_SUCCESS;
+}
+
 /* one multiplicative V-cycle on lv[top].b -> lv[top].x; x starts at zero on every level below the top, and on the
    top level too unless top_has_guess */
 static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_has_guess, void *stream)
@@ -1282,27 +1303,14 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     }
   }
   for (int l = 1; l <= top; ++l) {
-    mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
-    /* a z-slab also interpolates onto its in-domain ghost planes (from its coarse planes + coarse ghost planes): the
-       same arithmetic the owner does, so the fine ghost planes stay current without an exchange */
-    const int glo = Lv->distributed && Lv->kz0 > 0, ghi = Lv->distributed && Lv->kz0 + Lv->nzl < Lv->nz;
-    if (Lv->grid_transfer) { /* MatInterpolateAdd, matrix-free */
-      pmgk_grid_layout     GL;
-      const pmgk_st27_dims CD = level_dims(Cc);
-      PMG_CALL(pmg_grid_get_kernel_layout(Lv->g, &GL));
-      /* with omega = 1 a colour sweep never reads the old values of the colour it updates (the (1-omega) x term is
-         gone), so the colour the post-smoother visits first needs no correction: it is overwritten unread */
-      static int no_skip = -1;
-      if (no_skip < 0) no_skip = getenv("PMG_MG_PROLONG_BOTH") != NULL;
-      const int first = h->sweep_type == PMG_SOR_BACKWARD_SWEEP ? 1 : 0;
-      const int only  = (h->omega == 1.0 && h->nu >= 1 && !no_skip) ? 1 - first : -1;
-      PMG_KERNEL(pmgk_q1_prolong_add(&GL, &CD, Lv->cpos_dev, -glo, Lv->nzl + glo + ghi, only, Cc->x, Lv->x, stream));
-    } else if (Lv->nat_transfer) {
-      const pmgk_st27_dims FD = level_dims(Lv), CD = level_dims(Cc);
-      PMG_KERNEL(pmgk_st27_prolong_add(&FD, &CD, Lv->kz0 - glo, Lv->nzl + glo + ghi, Cc->x, Lv->x, stream));
-    } else {
-      PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, Cc->x, Lv->x, 1, stream)); /* MatInterpolateAdd */
-    }
+    mg_level *Lv = &h->lv[l];
+    /* with omega = 1 a colour sweep never reads the old values of the colour it updates (the (1-omega) x term is
+       gone), so the colour the post-smoother visits first needs no correction: it is overwritten unread */
+    static int no_skip = -1;
+    if (no_skip < 0) no_skip = getenv("PMG_MG_PROLONG_BOTH") != NULL;
+    const int first = h->sweep_type == PMG_SOR_BACKWARD_SWEEP ? 1 : 0;
+    const int only  = (h->omega == 1.0 && h->nu >= 1 && !no_skip) ? 1 - first : -1;
+    PMG_CALL(mg_prolong_add(h, l, h->lv[l - 1].x, Lv->x, only, stream));
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
   }
   return PMG_SUCCESS;
@@ -1360,6 +1368,85 @@ pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32
   PMG_CALL(lvl_from_layout(F, h->y_lay, y_nat, stream));
   if (counter_out) *counter_out = counter0 + (uint64_t)its;
   return PMG_SUCCESS;
+}
+
+/* ---- single-kernel entry points of one level (diagnostics: the full-size parity tests run ONE kernel of the V-cycle
+   on caller-supplied vectors in the level's own layout and compare sampled rows with the oracle) ---------------------- */
+static pmg_status level_checked(pmg_mgmc h, int32_t level, int need_coarser, mg_level **Lv)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(h->is_setup, PMG_ERR_ARG_WRONGSTATE, "call pmg_mgmc_setup first");
+  PMG_CHECK(!h->dist, PMG_ERR_SUP, "level diagnostics are a single-device feature");
+  PMG_CHECK(level >= (need_coarser ? 1 : 0) && level < h->nlevels, PMG_ERR_ARG_OUTOFRANGE, "level %d", level);
+  *Lv = &h->lv[level];
+  return PMG_SUCCESS;
+}
+
+/* kind: 0 = grid level (colour-partitioned cvec), 1 = class-stencil level, 2 = sliced-ELL level, 3 = dense coarsest level;
+   ld = vector length, off = position of natural index 0 for kinds 1 and 3 (plane-padded natural order), else 0 */
+pmg_status pmg_mgmc_get_level_layout(pmg_mgmc h, int32_t level, int32_t *kind, int64_t *ld, int64_t *off)
+{
+  mg_level *Lv;
+  PMG_CALL(level_checked(h, level, 0, &Lv));
+  if (kind) *kind = Lv->is_grid ? 0 : (Lv->is_st27 ? 1 : (Lv->mc ? 2 : 3));
+  if (ld) *ld = Lv->ld;
+  if (off) *off = Lv->padded ? Lv->off : 0;
+  return PMG_SUCCESS;
+}
+
+/* the 27 x 27 class table and the per-class noise scale of a class-stencil level, as the kernels use them */
+pmg_status pmg_mgmc_get_level_stencil(pmg_mgmc h, int32_t level, double *coef_host, double *sqrtdiag_host)
+{
+  mg_level *Lv;
+  PMG_CALL(level_checked(h, level, 0, &Lv));
+  PMG_CHECK(Lv->is_st27, PMG_ERR_ARG_WRONGSTATE, "level %d is not a class-stencil level", level);
+  if (coef_host) PMG_HIP(hipMemcpy(coef_host, Lv->st_coef, sizeof(double) * 27 * 27, hipMemcpyDeviceToHost));
+  if (sqrtdiag_host) PMG_HIP(hipMemcpy(sqrtdiag_host, h->scaled ? Lv->st_sqrtd_scaled : Lv->st_sqrtd, sizeof(double) * 27, hipMemcpyDeviceToHost));
+  return PMG_SUCCESS;
+}
+
+/* ONE directional sweep of the level sampler (all colours) with the raw (seed, counter) pair */
+pmg_status pmg_mgmc_level_sweep(pmg_mgmc h, int32_t level, int backward, int noisy, uint64_t seed, uint64_t counter, const double *b_lvl, double *x_lvl, void *stream)
+{
+  mg_level *Lv;
+  PMG_CALL(level_checked(h, level, 0, &Lv));
+  PMG_CHECK(b_lvl && x_lvl, PMG_ERR_ARG_NULL, "null vector");
+  PMG_CHECK(Lv->is_st27, PMG_ERR_SUP, "level %d: only class-stencil levels (use pmg_grid_* / pmg_mcsor_* for the others)", level);
+  pmgk_st27 S = Lv->st;
+  S.sqrtdiag  = h->scaled ? Lv->st_sqrtd_scaled : Lv->st_sqrtd;
+  PMG_KERNEL(pmgk_st27_sweep(&S, backward != 0, h->omega, noisy != 0, seed, counter, b_lvl, x_lvl, stream));
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_level_residual(pmg_mgmc h, int32_t level, const double *b_lvl, const double *x_lvl, double *r_lvl, void *stream)
+{
+  mg_level *Lv;
+  PMG_CALL(level_checked(h, level, 0, &Lv));
+  PMG_CHECK(b_lvl && x_lvl && r_lvl, PMG_ERR_ARG_NULL, "null vector");
+  if (Lv->is_grid) return pmg_grid_residual_cvec(Lv->g, b_lvl, x_lvl, r_lvl, stream);
+  if (Lv->is_st27) {
+    PMG_KERNEL(pmgk_st27_residual(&Lv->st, b_lvl, x_lvl, r_lvl, stream));
+    return PMG_SUCCESS;
+  }
+  PMG_CHECK(Lv->mc, PMG_ERR_SUP, "level %d has no residual kernel", level);
+  return pmg_mcsor_residual_layout(Lv->mc, b_lvl, x_lvl, r_lvl, stream);
+}
+
+/* b_coarse (level-1) = P^T r_fine (level); x_fine (level) += P e_coarse (level-1), both colours */
+pmg_status pmg_mgmc_level_restrict(pmg_mgmc h, int32_t level, double *r_fine, double *b_coarse, void *stream)
+{
+  mg_level *Lv;
+  PMG_CALL(level_checked(h, level, 1, &Lv));
+  PMG_CHECK(r_fine && b_coarse, PMG_ERR_ARG_NULL, "null vector");
+  return mg_restrict(h, level, r_fine, b_coarse, stream);
+}
+
+pmg_status pmg_mgmc_level_prolong_add(pmg_mgmc h, int32_t level, const double *e_coarse, double *x_fine, void *stream)
+{
+  mg_level *Lv;
+  PMG_CALL(level_checked(h, level, 1, &Lv));
+  PMG_CHECK(e_coarse && x_fine, PMG_ERR_ARG_NULL, "null vector");
+  return mg_prolong_add(h, level, e_coarse, x_fine, -1, stream);
 }
 
 pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)

@@ -105,6 +105,17 @@ def run_samples(sweep_planes, halo: SlabHalo, nz: int, b, y, its: int, sweep_typ
     return ctr
 
 
+def _all_ok(err, group, what: str) -> None:
+    """Agreement point: raises on EVERY rank if `err` is set on any rank (all-reduce MIN of an ok flag)."""
+    import torch
+    import torch.distributed as dist
+
+    flag = torch.tensor([0 if err else 1], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        raise RuntimeError(f"{what}: {err or 'failed on another rank'}")
+
+
 class RcclSlabDriver:
     """The C sample loop of pmg_dist.c: RCCL send/recv called straight from the host library, comm stream + events,
     no Python in the loop.  The 128-byte ncclUniqueId of rank 0 is broadcast through torch.distributed."""
@@ -121,13 +132,19 @@ class RcclSlabDriver:
         uid = None
         if world > 1 or loopback:
             buf = C.create_string_buffer(128)
+            err = None
             if rank == 0:
-                check(lib.pmg_dist_get_unique_id(pbytes, buf))
-            payload = [bytes(buf.raw)]
+                try:
+                    check(lib.pmg_dist_get_unique_id(pbytes, buf))
+                except Exception as e:  # noqa: BLE001 -- the other ranks are about to enter the broadcast: tell them
+                    err = f"{type(e).__name__}: {e}"
+            payload = [None if err else bytes(buf.raw)]
             if world > 1:
                 import torch.distributed as dist
 
                 dist.broadcast_object_list(payload, src=0, group=group)
+            if payload[0] is None:
+                raise RuntimeError(err or "rank 0 could not create the RCCL unique id")
             uid = C.create_string_buffer(payload[0], 128)
         check(lib.pmg_dist_create(grid._h, rank, world, uid, pbytes, int(loopback), C.byref(self._h)))
         self._grid = grid  # keep alive
@@ -179,22 +196,32 @@ class IpcSlabDriver(RcclSlabDriver):
             return
         import torch.distributed as dist
 
-        check(lib.pmg_dist_create_ipc(grid._h, rank, world, C.byref(self._h)))
-        nb = C.c_int32()
-        check(lib.pmg_dist_ipc_blob_bytes(C.byref(nb)))
-        blob = C.create_string_buffer(nb.value)
-        check(lib.pmg_dist_ipc_export(self._h, blob))
+        # every step that can fail on ONE rank alone (allocation, export, opening a peer's handle) is followed by an
+        # agreement, so that no rank is left waiting in a collective the failing rank never enters
+        err, blob, nb = None, None, C.c_int32()
+        try:  # local phase: allocate the receive block, export its handle
+            check(lib.pmg_dist_create_ipc(grid._h, rank, world, C.byref(self._h)))
+            check(lib.pmg_dist_ipc_blob_bytes(C.byref(nb)))
+            blob = C.create_string_buffer(nb.value)
+            check(lib.pmg_dist_ipc_export(self._h, blob))
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        _all_ok(err, group, "ipc: allocating / exporting the receive block")
         blobs = [None] * world
         dist.all_gather_object(blobs, bytes(blob.raw), group=group)
-        lo = C.create_string_buffer(blobs[rank - 1], nb.value) if rank > 0 else None
-        hi = C.create_string_buffer(blobs[rank + 1], nb.value) if rank < world - 1 else None
-        check(lib.pmg_dist_ipc_connect(self._h, lo, hi))
-        if world > 2:  # all-peer mappings: the all-gather of the distributed V-cycle becomes one step
-            bufs = [C.create_string_buffer(b_, nb.value) for b_ in blobs]
-            arr = (C.c_void_p * world)(*[C.cast(b_, C.c_void_p) for b_ in bufs])
-            check(lib.pmg_dist_ipc_connect_all(self._h, arr))
+        try:  # local phase: map the neighbours' (all peers') blocks
+            lo = C.create_string_buffer(blobs[rank - 1], nb.value) if rank > 0 else None
+            hi = C.create_string_buffer(blobs[rank + 1], nb.value) if rank < world - 1 else None
+            check(lib.pmg_dist_ipc_connect(self._h, lo, hi))
+            if world > 2:  # all-peer mappings: the all-gather of the distributed V-cycle becomes one step
+                bufs = [C.create_string_buffer(b_, nb.value) for b_ in blobs]
+                arr = (C.c_void_p * world)(*[C.cast(b_, C.c_void_p) for b_ in bufs])
+                check(lib.pmg_dist_ipc_connect_all(self._h, arr))
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        _all_ok(err, group, "ipc: opening the peers' memory handles")
         dist.barrier(group=group)
-        self._selftest(rank, world)
+        self._selftest(rank, world)  # no collective follows inside this constructor: a failure here is agreed on by the caller
 
     def _selftest(self, rank, world):
         """One round trip of a known pattern with both z-neighbours (peer copies into their blocks, flag words, copy

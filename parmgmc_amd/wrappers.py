@@ -315,6 +315,31 @@ class MGMC:
         check(lib.pmg_mgmc_get_level_matrix(self._h, level, w, C.byref(nr), C.byref(nnz), rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
         return rp, ci, v
 
+    # --- one kernel of the V-cycle on caller vectors in the level's own layout (diagnostics for full-size parity tests) ---
+    def level_layout(self, level: int):
+        """(kind, ld, off): kind 0 = grid cvec, 1 = class stencil, 2 = sliced-ELL, 3 = dense coarsest; natural index q of
+        kinds 1 and 3 sits at off + q"""
+        k, ld, off = C.c_int32(), C.c_int64(), C.c_int64()
+        check(lib.pmg_mgmc_get_level_layout(self._h, level, C.byref(k), C.byref(ld), C.byref(off)))
+        return k.value, ld.value, off.value
+
+    def level_stencil(self, level: int):
+        coef, sq = np.zeros((27, 27)), np.zeros(27)
+        check(lib.pmg_mgmc_get_level_stencil(self._h, level, coef.ctypes.data, sq.ctypes.data))
+        return coef, sq
+
+    def level_sweep(self, level: int, b, x, backward: bool = False, noisy: bool = False, seed: int = 0, counter: int = 0):
+        check(lib.pmg_mgmc_level_sweep(self._h, level, int(backward), int(noisy), seed, counter, _ptr(b), _ptr(x), _stream()))
+
+    def level_residual(self, level: int, b, x, r):
+        check(lib.pmg_mgmc_level_residual(self._h, level, _ptr(b), _ptr(x), _ptr(r), _stream()))
+
+    def level_restrict(self, level: int, r_fine, b_coarse):
+        check(lib.pmg_mgmc_level_restrict(self._h, level, _ptr(r_fine), _ptr(b_coarse), _stream()))
+
+    def level_prolong_add(self, level: int, e_coarse, x_fine):
+        check(lib.pmg_mgmc_level_prolong_add(self._h, level, _ptr(e_coarse), _ptr(x_fine), _stream()))
+
     def sample(self, b, y, its: int, seed: int, counter0: int = 0, guesszero: bool = False, callback=None) -> int:
         out = C.c_uint64()
         if callback is None:
