@@ -74,11 +74,15 @@ def test_grid_sweep_and_residual_rows_match_the_oracle(n, kappa):
         y1h = g.from_cvec(yc).cpu().numpy()
         want = O.grid7_rows_sweep(n, n, n, kappa, rows, bh, y0h, y1h, omega=omega, backward=backward)
         assert np.array_equal(y1h[rows], want), f"deterministic sweep, omega {omega}, backward {backward}: {int((y1h[rows] != want).sum())} of {len(rows)} rows differ"
-        if n == 256:  # negative control: the check is sensitive to the sweep order and to a single changed bit
+        if n == 256:  # negative control: the check notices a wrong sweep order and one wrong neighbour value
             assert not np.array_equal(y1h[rows], O.grid7_rows_sweep(n, n, n, kappa, rows, bh, y0h, y1h, omega=omega, backward=not backward))
-            y0x = y0h.copy()
-            y0x[rows[len(rows) // 2] + 1] = np.nextafter(y0x[rows[len(rows) // 2] + 1], 1e9)
-            assert not np.array_equal(y1h[rows], O.grid7_rows_sweep(n, n, n, kappa, rows, bh, y0x, y1h, omega=omega, backward=backward))
+            q = int(rows[len(rows) // 2])
+            q = q if q % n < n - 1 else q - 1  # a row with an east neighbour
+            y0x, y1x = y0h.copy(), y1h.copy()
+            y0x[q + 1] += 1.0
+            y1x[q + 1] += 1.0
+            bad = O.grid7_rows_sweep(n, n, n, kappa, np.array([q]), bh, y0x, y1x, omega=omega, backward=backward)
+            assert bad[0] != y1h[q]
         yc = g.to_cvec(y0)
         g.sample_cvec(bc, yc, 1, seed=0xCAFE, counter0=7, scaled=True)  # one mcgibbs sample = one noisy sweep, draw 7
         y1h = g.from_cvec(yc).cpu().numpy()
