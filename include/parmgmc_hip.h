@@ -14,7 +14,10 @@
  *   - "host" pointers are ordinary memory and are only read during the call (borrowed, never kept, like
  *     the reference's borrowed Mat arrays, src/pc_sorgibbs.c:35-38); "dev" pointers are HBM addresses of
  *     the current HIP device (hipMalloc / torch tensor.data_ptr()).
- *   - indices are 32-bit (PetscInt default), scalars are double (PetscScalar = PetscReal = double).
+ *   - indices: the reference builds against either PetscInt width (include/parmgmc/parmgmc.h:18-24); entry points
+ *     ending in _idx take `idx_width` = sizeof(PetscInt)*8 (32 or 64) with the index arrays as `const void *`, the
+ *     others are their 32-bit forms.  Inside, rows and stored entries per device are 32-bit; a 64-bit matrix whose
+ *     local sizes do not fit fails with PETSC_ERR_ARG_OUTOFRANGE.  Scalars are double (PetscScalar = PetscReal).
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All device work is enqueued on
  *     it and NOT synchronised: calls return as soon as the work is queued unless stated otherwise.
  *   - objects are not thread safe (the reference is single threaded per rank, src/parmgmc.c:38-42).
@@ -75,6 +78,9 @@ typedef struct pmg_mcsor_s *pmg_mcsor; /* opaque, like `struct _MCSOR { void *ct
    MatSeqAIJGetCSRAndMemType, src/mc_sor.c:250).  Copies nothing yet; the arrays must stay valid until
    pmg_mcsor_setup returns.  omega = 1, sweep = forward, colouring = GREEDY. */
 pmg_status pmg_mcsor_create_csr(int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host, pmg_mcsor *mc);
+/* the same for either PetscInt width (idx_width = 32 | 64); 64-bit arrays are narrowed to checked 32-bit copies at once,
+   so they need not outlive the call */
+pmg_status pmg_mcsor_create_csr_idx(int64_t n, const void *rowptr_host, const void *colidx_host, const double *vals_host, int idx_width, pmg_mcsor *mc);
 /* Choose the colouring before setup.  user_colors_host (n entries, colours 0..ncolors-1) only for USER. */
 pmg_status pmg_mcsor_set_coloring(pmg_mcsor mc, int rule, const int32_t *user_colors_host);
 /* MCSORSetUp (src/mc_sor.c:553-605): diagonal pointers (:126-150), colouring (:441-454), idiag (:114-124);
@@ -235,6 +241,8 @@ pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr_host, const int3
 /* the same sampler for a MATLRC operator A + B S B^T (src/pc_chols.c:119-153: the update is added to the matrix
    before it is factored); B is n x k column-major, S the k diagonal entries, both on the host */
 pmg_status pmg_chol_create_csr_lowrank(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int32_t k, const double *B_host, const double *S_host, pmg_chol *out);
+/* either PetscInt width (idx_width = 32 | 64); k = 0 for a plain AIJ matrix */
+pmg_status pmg_chol_create_csr_idx(int64_t n, const void *rowptr, const void *colidx, const double *vals, int idx_width, int32_t k, const double *B_host, const double *S_host, pmg_chol *out);
 /* the lower factor L, column-major n*n on the host (upper part zero) */
 pmg_status pmg_chol_get_factor(pmg_chol ch, double *L_colmajor_host);
 /* PCApply_CholSampler (src/pc_chols.c:262-291): y = L^-T (L^-1 b + xi), xi = row-stream normals of
@@ -274,6 +282,9 @@ pmg_status pmg_mgmc_create_hierarchy(int32_t levels, pmg_mgmc *mg);
 pmg_status pmg_mgmc_set_level_operator(pmg_mgmc mg, int32_t level, int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host);
 /* interpolation from level-1 (ncols unknowns) to `level` (nrows unknowns), level >= 1 */
 pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc mg, int32_t level, int32_t nrows, int32_t ncols, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host);
+/* both for either PetscInt width (idx_width = 32 | 64) */
+pmg_status pmg_mgmc_set_level_operator_idx(pmg_mgmc mg, int32_t level, int64_t n, const void *rowptr_host, const void *colidx_host, const double *vals_host, int idx_width);
+pmg_status pmg_mgmc_set_level_interpolation_idx(pmg_mgmc mg, int32_t level, int64_t nrows, int64_t ncols, const void *rowptr_host, const void *colidx_host, const double *vals_host, int idx_width);
 /* -mg_levels_pc_type sorgibbs (scaled = 0, omega = 1) | mcgibbs (scaled = 1, any omega, any sweep type);
    its = -mg_levels_ksp_max_it */
 pmg_status pmg_mgmc_set_smoother(pmg_mgmc mg, int scaled, double omega, int sweep_type, int32_t its);

@@ -74,6 +74,10 @@ _sig = {
     "pmg_version": (C.c_char_p, []),
     "pmg_gpu_arch": (C.c_char_p, []),
     "pmg_mcsor_create_csr": (_int, [_i32, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pmg_mcsor_create_csr_idx": (_int, [_i64, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
+    "pmg_mgmc_set_level_operator_idx": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _int]),
+    "pmg_mgmc_set_level_interpolation_idx": (_int, [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _int]),
+    "pmg_chol_create_csr_idx": (_int, [_i64, _vp, _vp, _vp, _int, _i32, _vp, _vp, C.POINTER(_vp)]),
     "pmg_mcsor_set_coloring": (_int, [_vp, _int, _vp]),
     "pmg_mcsor_setup": (_int, [_vp]),
     "pmg_mcsor_set_omega": (_int, [_vp, _dbl]),

@@ -23,6 +23,18 @@ pmg_status pmg_chol_create_csr(int32_t n, const int32_t *rowptr, const int32_t *
   return pmg_chol_create_csr_lowrank(n, rowptr, colidx, vals, 0, NULL, NULL, out);
 }
 
+pmg_status pmg_chol_create_csr_idx(int64_t n, const void *rowptr, const void *colidx, const double *vals, int idx_width, int32_t k, const double *B_host, const double *S_host, pmg_chol *out)
+{
+  const int32_t *rp, *ci;
+  int32_t       *rpo, *cio;
+  PMG_CHECK(out, PMG_ERR_ARG_NULL, "null output handle");
+  PMG_CALL(pmg_narrow_csr(n, n, rowptr, colidx, idx_width, &rp, &ci, &rpo, &cio));
+  pmg_status st = pmg_chol_create_csr_lowrank((int32_t)n, rp, ci, vals, k, B_host, S_host, out); /* copies what it needs */
+  free(rpo);
+  free(cio);
+  return st;
+}
+
 /* PCSetUp_CholSampler on a MATLRC operator (src/pc_chols.c:119-153): the factored matrix is P = A + B S B^T, formed
    explicitly (MatMatTransposeMult + MatAXPY there; a dense rank-k accumulation here, the matrix is dense anyway). */
 pmg_status pmg_chol_create_csr_lowrank(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int32_t k, const double *B_host, const double *S_host, pmg_chol *out)

@@ -49,3 +49,50 @@ pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t
   PMG_KERNEL(pmgk_fill_normal_rows(n, seed, counter, x_dev, stream));
   return PMG_SUCCESS;
 }
+
+/* Index arrays of the caller's PetscInt width (reference include/parmgmc/parmgmc.h:18-24 builds against 32- and 64-bit
+   PetscInt; the arrays come from MatSeqAIJGetCSRAndMemType, src/mc_sor.c:250).  The library's own index type is 32-bit
+   (an MI355X holds far fewer than 2^31 rows of an AIJ matrix per device): width 32 borrows the arrays, width 64 makes
+   checked 32-bit copies (*rp_own / *ci_own, malloc'ed, the caller frees them) and fails with PETSC_ERR_ARG_OUTOFRANGE
+   if a row pointer or a column index does not fit. */
+pmg_status pmg_narrow_csr(int64_t nrows, int64_t ncols, const void *rowptr, const void *colidx, int idx_width, const int32_t **rp, const int32_t **ci, int32_t **rp_own, int32_t **ci_own)
+{
+  *rp_own = *ci_own = NULL;
+  PMG_CHECK(idx_width == 32 || idx_width == 64, PMG_ERR_ARG_OUTOFRANGE, "idx_width = %d (32 or 64: sizeof(PetscInt) * 8)", idx_width);
+  PMG_CHECK(nrows >= 0 && nrows < 2147483647 && ncols < 2147483647, PMG_ERR_ARG_OUTOFRANGE, "%lld x %lld exceeds the 32-bit local sizes of the library", (long long)nrows, (long long)ncols);
+  PMG_CHECK(rowptr, PMG_ERR_ARG_NULL, "null row pointer array");
+  if (idx_width == 32) {
+    *rp = (const int32_t *)rowptr;
+    *ci = (const int32_t *)colidx;
+    return PMG_SUCCESS;
+  }
+  const int64_t *rp64 = (const int64_t *)rowptr, *ci64 = (const int64_t *)colidx;
+  const int64_t  nnz  = rp64[nrows];
+  PMG_CHECK(nnz >= 0 && nnz < 2147483647, PMG_ERR_ARG_OUTOFRANGE, "%lld stored entries exceed the 32-bit row pointers of the library", (long long)nnz);
+  PMG_CHECK(ci64 || nnz == 0, PMG_ERR_ARG_NULL, "null column index array");
+  int32_t *a = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nrows + 1)), *b = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+  if (!a || !b) {
+    free(a);
+    free(b);
+    PMG_FAIL(PMG_ERR_MEM, "out of host memory");
+  }
+  for (int64_t r = 0; r <= nrows; ++r) {
+    if (rp64[r] < 0 || rp64[r] > nnz || (r > 0 && rp64[r] < rp64[r - 1])) {
+      free(a);
+      free(b);
+      PMG_FAIL(PMG_ERR_ARG_WRONG, "row pointer %lld = %lld is not monotone within [0, %lld]", (long long)r, (long long)rp64[r], (long long)nnz);
+    }
+    a[r] = (int32_t)rp64[r];
+  }
+  for (int64_t k = 0; k < nnz; ++k) {
+    if (ci64[k] < 0 || ci64[k] >= ncols) {
+      free(a);
+      free(b);
+      PMG_FAIL(PMG_ERR_ARG_OUTOFRANGE, "column index %lld at entry %lld outside [0, %lld)", (long long)ci64[k], (long long)k, (long long)ncols);
+    }
+    b[k] = (int32_t)ci64[k];
+  }
+  *rp = *rp_own = a;
+  *ci = *ci_own = b;
+  return PMG_SUCCESS;
+}

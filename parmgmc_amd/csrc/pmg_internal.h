@@ -61,6 +61,7 @@ pmg_status pmg_mcsor_set_idiag_by_division(pmg_mcsor mc, int on); /* PCPARSOR's 
 pmg_status pmg_parsor_build_dataflow(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int32_t nparts, const int32_t *row_starts, const int32_t *proccols_in, int32_t **e_rowptr, int32_t **e_colidx, double **e_vals, int32_t **e_colors, int32_t *nlevels_out, int32_t *proccols_out, int32_t *classes_out);
 int        pmg_invert_small(int k, double *a_colmajor, double *inv); /* Gauss-Jordan, partial pivoting; a is overwritten; nonzero = singular */
 
+pmg_status pmg_narrow_csr(int64_t nrows, int64_t ncols, const void *rowptr, const void *colidx, int idx_width, const int32_t **rp, const int32_t **ci, int32_t **rp_own, int32_t **ci_own);
 /* device allocation helpers (zero-filled) */
 pmg_status pmg_dev_alloc(void **p, size_t bytes);
 pmg_status pmg_dev_upload(void **p, const void *host, size_t bytes);

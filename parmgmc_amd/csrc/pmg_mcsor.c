@@ -15,6 +15,7 @@ struct pmg_mcsor_s {
   int32_t        n;
   const int32_t *rowptr, *colidx;
   const double  *vals;
+  int32_t       *rowptr_own, *colidx_own; /* 32-bit copies of a 64-bit PetscInt matrix (pmg_mcsor_create_csr_idx) */
   /* options */
   double   omega;
   int      omega_changed;
@@ -116,6 +117,25 @@ pmg_status pmg_mcsor_create_csr(int32_t n, const int32_t *rowptr, const int32_t 
   mc->type          = PMG_SOR_FORWARD_SWEEP; /* src/mc_sor.c:636 */
   mc->rule          = PMG_COLORING_GREEDY;
   *out              = mc;
+  return PMG_SUCCESS;
+}
+
+/* the same for either PetscInt width (include/parmgmc/parmgmc.h:18-24): idx_width = sizeof(PetscInt) * 8 */
+pmg_status pmg_mcsor_create_csr_idx(int64_t n, const void *rowptr, const void *colidx, const double *vals, int idx_width, pmg_mcsor *out)
+{
+  PMG_CHECK(out, PMG_ERR_ARG_NULL, "null output handle");
+  *out = NULL;
+  const int32_t *rp, *ci;
+  int32_t       *rpo, *cio;
+  PMG_CALL(pmg_narrow_csr(n, n, rowptr, colidx, idx_width, &rp, &ci, &rpo, &cio));
+  pmg_status st = pmg_mcsor_create_csr((int32_t)n, rp, ci, vals, out);
+  if (st) {
+    free(rpo);
+    free(cio);
+    return st;
+  }
+  (*out)->rowptr_own = rpo;
+  (*out)->colidx_own = cio;
   return PMG_SUCCESS;
 }
 
@@ -580,6 +600,8 @@ pmg_status pmg_mcsor_destroy(pmg_mcsor *mc)
   pmg_lrc_destroy(&(*mc)->lrc);
   mcsor_free_setup(*mc);
   free((*mc)->user_colors);
+  free((*mc)->rowptr_own);
+  free((*mc)->colidx_own);
   free(*mc);
   *mc = NULL;
   return PMG_SUCCESS;

@@ -57,6 +57,7 @@ typedef struct {
   hcsr A_host, P_host;
   /* caller-supplied hierarchy (borrowed host CSR until set-up) */
   hcsr A_user, P_user;
+  int32_t *A_rp_own, *A_ci_own, *P_rp_own, *P_ci_own; /* 32-bit copies of 64-bit PetscInt arrays, freed after set-up */
 } mg_level;
 
 struct pmg_mgmc_s {
@@ -412,6 +413,49 @@ pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc h, int32_t level, int32_t n
   return PMG_SUCCESS;
 }
 
+/* the two calls above for either PetscInt width: idx_width = sizeof(PetscInt) * 8 */
+pmg_status pmg_mgmc_set_level_operator_idx(pmg_mgmc h, int32_t level, int64_t n, const void *rowptr, const void *colidx, const double *vals, int idx_width)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(level >= 0 && level < h->nlevels, PMG_ERR_ARG_OUTOFRANGE, "level %d", level);
+  const int32_t *rp, *ci;
+  int32_t       *rpo, *cio;
+  PMG_CALL(pmg_narrow_csr(n, n, rowptr, colidx, idx_width, &rp, &ci, &rpo, &cio));
+  pmg_status st = pmg_mgmc_set_level_operator(h, level, (int32_t)n, rp, ci, vals);
+  mg_level  *Lv = &h->lv[level];
+  if (!st) {
+    free(Lv->A_rp_own);
+    free(Lv->A_ci_own);
+    Lv->A_rp_own = rpo;
+    Lv->A_ci_own = cio;
+  } else {
+    free(rpo);
+    free(cio);
+  }
+  return st;
+}
+
+pmg_status pmg_mgmc_set_level_interpolation_idx(pmg_mgmc h, int32_t level, int64_t nrows, int64_t ncols, const void *rowptr, const void *colidx, const double *vals, int idx_width)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(level >= 1 && level < h->nlevels, PMG_ERR_ARG_OUTOFRANGE, "level %d", level);
+  const int32_t *rp, *ci;
+  int32_t       *rpo, *cio;
+  PMG_CALL(pmg_narrow_csr(nrows, ncols, rowptr, colidx, idx_width, &rp, &ci, &rpo, &cio));
+  pmg_status st = pmg_mgmc_set_level_interpolation(h, level, (int32_t)nrows, (int32_t)ncols, rp, ci, vals);
+  mg_level  *Lv = &h->lv[level];
+  if (!st) {
+    free(Lv->P_rp_own);
+    free(Lv->P_ci_own);
+    Lv->P_rp_own = rpo;
+    Lv->P_ci_own = cio;
+  } else {
+    free(rpo);
+    free(cio);
+  }
+  return st;
+}
+
 pmg_status pmg_mgmc_set_smoother(pmg_mgmc h, int scaled, double omega, int sweep_type, int32_t its)
 {
   PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
@@ -636,6 +680,11 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     mg_level *Lv = &h->lv[l];
     memset(&Lv->A_user, 0, sizeof Lv->A_user); /* borrowed arrays are released */
     memset(&Lv->P_user, 0, sizeof Lv->P_user);
+    free(Lv->A_rp_own);
+    free(Lv->A_ci_own);
+    free(Lv->P_rp_own);
+    free(Lv->P_ci_own);
+    Lv->A_rp_own = Lv->A_ci_own = Lv->P_rp_own = Lv->P_ci_own = NULL;
     PMG_CALL(pmg_dev_alloc((void **)&Lv->b, sizeof(double) * (size_t)Lv->ld));
     PMG_CALL(pmg_dev_alloc((void **)&Lv->x, sizeof(double) * (size_t)Lv->ld));
     PMG_CALL(pmg_dev_alloc((void **)&Lv->r, sizeof(double) * (size_t)Lv->ld));
@@ -1476,6 +1525,10 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
     pmg_dev_free(Lv->R_val);
     hcsr_free(&Lv->A_host);
     hcsr_free(&Lv->P_host);
+    free(Lv->A_rp_own);
+    free(Lv->A_ci_own);
+    free(Lv->P_rp_own);
+    free(Lv->P_ci_own);
   }
   pmg_chol_destroy(&h->chol);
   pmg_dev_free(h->y_lay);

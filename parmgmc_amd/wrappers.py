@@ -28,13 +28,18 @@ def _ptr(t):
 class MCSOR:
     """MCSOR on an assembled AIJ matrix (reference include/parmgmc/mc_sor.h:21-30)."""
 
-    def __init__(self, rowptr, colidx, vals, coloring=capi.COLORING_GREEDY, user_colors=None):
-        self._rowptr = np.ascontiguousarray(rowptr, np.int32)
-        self._colidx = np.ascontiguousarray(colidx, np.int32)
+    def __init__(self, rowptr, colidx, vals, coloring=capi.COLORING_GREEDY, user_colors=None, idx_width=32):
+        """idx_width 64: the index arrays cross the boundary as 64-bit PetscInt (pmg_mcsor_create_csr_idx)"""
+        it = np.int64 if idx_width == 64 else np.int32
+        self._rowptr = np.ascontiguousarray(rowptr, it)
+        self._colidx = np.ascontiguousarray(colidx, it)
         self._vals = np.ascontiguousarray(vals, np.float64)
         self.n = len(self._rowptr) - 1
         self._h = C.c_void_p()
-        check(lib.pmg_mcsor_create_csr(self.n, self._rowptr.ctypes.data, self._colidx.ctypes.data, self._vals.ctypes.data, C.byref(self._h)))
+        if idx_width == 32:
+            check(lib.pmg_mcsor_create_csr(self.n, self._rowptr.ctypes.data, self._colidx.ctypes.data, self._vals.ctypes.data, C.byref(self._h)))
+        else:
+            check(lib.pmg_mcsor_create_csr_idx(self.n, self._rowptr.ctypes.data, self._colidx.ctypes.data, self._vals.ctypes.data, idx_width, C.byref(self._h)))
         uc = None
         if user_colors is not None:
             uc = np.ascontiguousarray(user_colors, np.int32)
@@ -218,12 +223,18 @@ class GridMCSOR:
 class CholSampler:
     """Exact coarse sampler (reference PCCHOLSAMPLER dense path, src/pc_chols.c:174-291)."""
 
-    def __init__(self, rowptr, colidx, vals, B=None, S=None):
+    def __init__(self, rowptr, colidx, vals, B=None, S=None, idx_width=32):
         """B (n x k), S (k): factor the MATLRC operator A + B diag(S) B^T instead (src/pc_chols.c:119-153)."""
-        rp, ci, v = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colidx, np.int32), np.ascontiguousarray(vals, np.float64)
+        it = np.int64 if idx_width == 64 else np.int32
+        rp, ci, v = np.ascontiguousarray(rowptr, it), np.ascontiguousarray(colidx, it), np.ascontiguousarray(vals, np.float64)
         self.n = len(rp) - 1
         self._h = C.c_void_p()
-        if B is None:
+        if idx_width != 32:
+            k = 0 if B is None else np.asarray(B).shape[1]
+            Bf = None if B is None else np.asfortranarray(B, np.float64)
+            Sf = None if S is None else np.ascontiguousarray(S, np.float64)
+            check(lib.pmg_chol_create_csr_idx(self.n, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, idx_width, k, None if Bf is None else Bf.ctypes.data, None if Sf is None else Sf.ctypes.data, C.byref(self._h)))
+        elif B is None:
             check(lib.pmg_chol_create_csr(self.n, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, C.byref(self._h)))
         else:
             B = np.asfortranarray(B, np.float64)
@@ -261,24 +272,33 @@ class MGMC:
         self.levels = levels
 
     @classmethod
-    def from_hierarchy(cls, operators, interpolations):
+    def from_hierarchy(cls, operators, interpolations, idx_width=32):
         """operators[l] = (rowptr, colidx, vals) of level l (0 = coarsest); interpolations[l] (l >= 1) = CSR triple of
-        the prolongation from level l-1 to level l (reference src/pc_gamgmc.c:165-176: what PCMG holds)."""
+        the prolongation from level l-1 to level l (reference src/pc_gamgmc.c:165-176: what PCMG holds).  idx_width 64:
+        the index arrays cross the boundary as 64-bit PetscInt and need not outlive the calls."""
         self = cls.__new__(cls)
         levels = len(operators)
         self._h = C.c_void_p()
         self.levels = levels
         self._keep = []
+        it = np.int64 if idx_width == 64 else np.int32
         check(lib.pmg_mgmc_create_hierarchy(levels, C.byref(self._h)))
         for l, (rp, ci, v) in enumerate(operators):
-            rp, ci, v = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(v, np.float64)
-            self._keep.append((rp, ci, v))
-            check(lib.pmg_mgmc_set_level_operator(self._h, l, len(rp) - 1, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+            rp, ci, v = np.ascontiguousarray(rp, it), np.ascontiguousarray(ci, it), np.ascontiguousarray(v, np.float64)
+            self._keep.append((rp, ci, v) if idx_width == 32 else (v,))
+            if idx_width == 32:
+                check(lib.pmg_mgmc_set_level_operator(self._h, l, len(rp) - 1, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+            else:
+                check(lib.pmg_mgmc_set_level_operator_idx(self._h, l, len(rp) - 1, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, idx_width))
         for l in range(1, levels):
             rp, ci, v = interpolations[l]
-            rp, ci, v = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(v, np.float64)
-            self._keep.append((rp, ci, v))
-            check(lib.pmg_mgmc_set_level_interpolation(self._h, l, len(rp) - 1, len(operators[l - 1][0]) - 1, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+            rp, ci, v = np.ascontiguousarray(rp, it), np.ascontiguousarray(ci, it), np.ascontiguousarray(v, np.float64)
+            self._keep.append((rp, ci, v) if idx_width == 32 else (v,))
+            nc = len(operators[l - 1][0]) - 1
+            if idx_width == 32:
+                check(lib.pmg_mgmc_set_level_interpolation(self._h, l, len(rp) - 1, nc, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+            else:
+                check(lib.pmg_mgmc_set_level_interpolation_idx(self._h, l, len(rp) - 1, nc, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, idx_width))
         self.n = len(operators[-1][0]) - 1
         return self
 

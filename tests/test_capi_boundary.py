@@ -79,3 +79,34 @@ def test_grid_coloring_is_bit_exact_red_black():
     lib.pmg_grid_get_coloring(h, col.ctypes.data)
     assert np.array_equal(col, O.coloring_redblack(6, 5, 4)[30:90])
     lib.pmg_grid_destroy(C.byref(h))
+
+
+def test_idx_width_entry_points_check_their_arguments():
+    """64-bit PetscInt builds (reference include/parmgmc/parmgmc.h:18-24): the _idx entry points narrow the index arrays
+    with range checks; no GPU is touched before set-up."""
+    rp = np.array([0, 2, 4, 6], np.int64)
+    ci = np.array([0, 1, 0, 1, 1, 2], np.int64)
+    v = np.array([2.0, -1, -1, 2, -1, 2])
+    h = C.c_void_p()
+    assert lib.pmg_mcsor_create_csr_idx(3, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 64, C.byref(h)) == 0
+    n = C.c_int32()
+    assert lib.pmg_mcsor_destroy(C.byref(h)) == 0
+    assert lib.pmg_mcsor_create_csr_idx(3, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 16, C.byref(h)) == 63
+    assert b"idx_width" in lib.pmg_last_error_string()
+    bad = ci.copy()
+    bad[3] = 1 << 33
+    assert lib.pmg_mcsor_create_csr_idx(3, rp.ctypes.data, bad.ctypes.data, v.ctypes.data, 64, C.byref(h)) == 63
+    assert not h.value
+    rpbad = np.array([0, 4, 2, 6], np.int64)
+    assert lib.pmg_mcsor_create_csr_idx(3, rpbad.ctypes.data, ci.ctypes.data, v.ctypes.data, 64, C.byref(h)) == 62
+    assert lib.pmg_mcsor_create_csr_idx(1 << 40, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 64, C.byref(h)) == 63
+    # 32-bit arrays through the same entry point
+    assert lib.pmg_mcsor_create_csr_idx(3, rp.astype(np.int32).ctypes.data, ci.astype(np.int32).ctypes.data, v.ctypes.data, 32, C.byref(h)) == 0
+    assert lib.pmg_mcsor_destroy(C.byref(h)) == 0
+    mg = C.c_void_p()
+    assert lib.pmg_mgmc_create_hierarchy(2, C.byref(mg)) == 0
+    assert lib.pmg_mgmc_set_level_operator_idx(mg, 1, 3, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 64) == 0
+    assert lib.pmg_mgmc_set_level_operator_idx(mg, 5, 3, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 64) == 63
+    prp, pci, pv = np.array([0, 1, 2, 3], np.int64), np.array([0, 0, 7], np.int64), np.ones(3)
+    assert lib.pmg_mgmc_set_level_interpolation_idx(mg, 1, 3, 1, prp.ctypes.data, pci.ctypes.data, pv.ctypes.data, 64) == 63  # column 7 of 1
+    assert lib.pmg_mgmc_destroy(C.byref(mg)) == 0
