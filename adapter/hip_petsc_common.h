@@ -1,0 +1,174 @@
+/*
+ * hip_petsc_common.h -- what the PETSc-side constructors of libparmgmc_hip share.
+ *
+ * Compiled only with -DPARMGMC_HIP_HAVE_PETSC inside a ParMGMC + PETSc tree (see adapter/README.md); PETSc is not in
+ * the build image of this repository, so tests/test_adapter_syntax.py can only check that the files are valid C
+ * against a declaration-only transcription of the PETSc calls they make.
+ *
+ * Vec staging.  The reference reads and writes host arrays (VecGetArray, reference src/mc_sor.c:252-255).  The
+ * device kernels need HBM addresses:
+ *   - a Vec that lives on the device (VECHIP, PETSc built --with-hip) hands its device array over unchanged;
+ *   - a host Vec is staged ONCE PER CALL of apply / applyrichardson (not once per sample): b and y are copied to
+ *     device buffers the PC owns, all `its` samples run there, and y is copied back at the end -- and before every
+ *     sample callback, which must see the sample on the host (reference src/pc_mcgibbs.c:183).
+ */
+#ifndef PARMGMC_HIP_PETSC_COMMON_H
+#define PARMGMC_HIP_PETSC_COMMON_H
+#ifdef PARMGMC_HIP_HAVE_PETSC
+
+#include <petsc/private/pcimpl.h> /* pc->ops, pc->data, pc->pmat: as reference src/pc_sorgibbs.c:14 */
+#include <petscksp.h>
+#include <petscmat.h>
+#include <petscvec.h>
+#include <parmgmc/parmgmc.h> /* PCRegisterSetSampleCallback, ParMGMCGetPetscRandom, PetscOptionItems_ARG, MULTICOL_SOR */
+#include <hip/hip_runtime_api.h>
+#include <parmgmc_hip.h>
+
+/* PetscCall for the C-ABI: its status codes ARE PetscErrorCode numbers (include/parmgmc_hip.h), the text comes along */
+#define PMGCall(expr) \
+  do { \
+    int pmg_s_ = (expr); \
+    PetscCheck(pmg_s_ == 0, PETSC_COMM_SELF, (PetscErrorCode)pmg_s_, "libparmgmc_hip: %s", pmg_last_error_string()); \
+  } while (0)
+#define PMGHip(expr) \
+  do { \
+    hipError_t pmg_e_ = (expr); \
+    PetscCheck(pmg_e_ == hipSuccess, PETSC_COMM_SELF, PETSC_ERR_GPU, "%s: %s", #expr, hipGetErrorString(pmg_e_)); \
+  } while (0)
+
+#define PMG_IDX_WIDTH ((int)(8 * sizeof(PetscInt))) /* 32, or 64 with --with-64-bit-indices */
+
+/* one vector checked out of PETSc for the duration of a call */
+typedef struct {
+  Vec          v;
+  PetscScalar *arr;    /* what PETSc gave us (host or device address) */
+  double      *dev;    /* what the kernels use */
+  PetscBool    staged; /* dev is a copy of a host array */
+  PetscBool    write;
+  PetscInt     n;
+} HipVecAccess;
+
+/* growable device buffer owned by a PC */
+typedef struct {
+  double  *buf;
+  PetscInt cap;
+} HipStageBuf;
+
+static inline PetscErrorCode HipStageBufFree(HipStageBuf *s)
+{
+  PetscFunctionBeginUser;
+  if (s->buf) PMGHip(hipFree(s->buf));
+  s->buf = NULL;
+  s->cap = 0;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static inline PetscErrorCode HipVecGet(Vec v, PetscBool write, HipStageBuf *stage, HipVecAccess *a)
+{
+  PetscMemType mt;
+
+  PetscFunctionBeginUser;
+  a->v     = v;
+  a->write = write;
+  PetscCall(VecGetLocalSize(v, &a->n));
+  if (write) PetscCall(VecGetArrayAndMemType(v, &a->arr, &mt));
+  else PetscCall(VecGetArrayReadAndMemType(v, (const PetscScalar **)&a->arr, &mt));
+  if (PetscMemTypeDevice(mt)) {
+    a->dev    = (double *)a->arr;
+    a->staged = PETSC_FALSE;
+  } else {
+    if (stage->cap < a->n) {
+      if (stage->buf) PMGHip(hipFree(stage->buf));
+      PMGHip(hipMalloc((void **)&stage->buf, sizeof(double) * (size_t)(a->n > 0 ? a->n : 1)));
+      stage->cap = a->n;
+    }
+    PMGHip(hipMemcpy(stage->buf, a->arr, sizeof(double) * (size_t)a->n, hipMemcpyHostToDevice));
+    a->dev    = stage->buf;
+    a->staged = PETSC_TRUE;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* make the host side of a staged, written vector current (no-op for device Vecs); waits for the stream */
+static inline PetscErrorCode HipVecSyncHost(HipVecAccess *a, hipStream_t stream)
+{
+  PetscFunctionBeginUser;
+  PMGHip(hipStreamSynchronize(stream));
+  if (a->staged && a->write) PMGHip(hipMemcpy(a->arr, a->dev, sizeof(double) * (size_t)a->n, hipMemcpyDeviceToHost));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static inline PetscErrorCode HipVecRestore(HipVecAccess *a, hipStream_t stream)
+{
+  PetscFunctionBeginUser;
+  if (a->write) {
+    PetscCall(HipVecSyncHost(a, stream));
+    PetscCall(VecRestoreArrayAndMemType(a->v, &a->arr));
+  } else {
+    PetscCall(VecRestoreArrayReadAndMemType(a->v, (const PetscScalar **)&a->arr));
+  }
+  a->arr = NULL;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* Calls the user's sample callback with y readable on the host side of the Vec, as the reference does after every
+   sample (src/pc_mcgibbs.c:183, src/pc_sorgibbs.c:71, src/pc_gamgmc.c:258): hand the array back to PETSc for the
+   duration of the callback, then check it out again (same addresses). */
+static inline PetscErrorCode HipCallSampleCallback(PetscErrorCode (*scb)(PetscInt, Vec, void *), void *ctx, PetscInt it, HipVecAccess *y, hipStream_t stream)
+{
+  PetscMemType mt;
+
+  PetscFunctionBeginUser;
+  PetscCall(HipVecSyncHost(y, stream));
+  PetscCall(VecRestoreArrayAndMemType(y->v, &y->arr));
+  PetscCall(scb(it, y->v, ctx));
+  PetscCall(VecGetArrayAndMemType(y->v, &y->arr, &mt));
+  if (y->staged) PMGHip(hipMemcpy(y->dev, y->arr, sizeof(double) * (size_t)y->n, hipMemcpyHostToDevice)); /* the callback may have changed y */
+  else y->dev = (double *)y->arr;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* seed of the library's counter-based noise = seed of ParMGMC's global PetscRandom (reference src/parmgmc.c:56-68,
+   -random_seed): one stream definition for all PCs of a process, like the reference's shared generator */
+static inline PetscErrorCode HipNoiseSeed(uint64_t *seed)
+{
+  PetscRandom r;
+  PetscInt64  s;
+
+  PetscFunctionBeginUser;
+  PetscCall(ParMGMCGetPetscRandom(&r));
+  PetscCall(PetscRandomGetSeed(r, &s));
+  PetscCall(PetscRandomDestroy(&r)); /* drop the reference ParMGMCGetPetscRandom took */
+  *seed = (uint64_t)s;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* MATLRC pieces as host arrays: B dense n x k (column-major, leading dimension n) and S (k) -- MatLRCGetMats as
+   reference src/mc_sor.c:576.  *Bcopy is PetscMalloc'ed when B's leading dimension is not n (caller frees). */
+static inline PetscErrorCode HipGetLRC(Mat lrc, Mat *A, PetscInt *k, const PetscScalar **B, PetscScalar **Bcopy, Mat *Bmat, Vec *S)
+{
+  PetscInt n, lda;
+
+  PetscFunctionBeginUser;
+  *Bcopy = NULL;
+  PetscCall(MatLRCGetMats(lrc, A, Bmat, S, NULL));
+  PetscCall(MatGetSize(*Bmat, &n, k));
+  PetscCall(MatDenseGetLDA(*Bmat, &lda));
+  PetscCall(MatDenseGetArrayRead(*Bmat, B));
+  if (lda != n) {
+    PetscCall(PetscMalloc1((size_t)n * (size_t)*k, Bcopy));
+    for (PetscInt c = 0; c < *k; ++c) PetscCall(PetscArraycpy(*Bcopy + (size_t)n * c, *B + (size_t)lda * c, n));
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PETSC_EXTERN PetscErrorCode PCCreate_HipSORGibbs(PC);
+PETSC_EXTERN PetscErrorCode PCCreate_HipMulticolorGibbs(PC);
+PETSC_EXTERN PetscErrorCode PCCreate_HipGAMGMC(PC);
+PETSC_EXTERN PetscErrorCode PCCreate_HipCholSampler(PC);
+/* PCRegister of the four names above under the reference's type names "sorgibbs", "mcgibbs", "gamgmc",
+   "cholsampler": call it from ParMGMCRegisterPCAll (reference src/parmgmc.c:44-54) in place of the CPU constructors */
+PETSC_EXTERN PetscErrorCode ParMGMCHipRegisterPCAll(void);
+
+#endif /* PARMGMC_HIP_HAVE_PETSC */
+#endif

@@ -52,6 +52,9 @@ typedef int pmg_status;
 
 /* Message of the last failing call on this thread ("" if none). */
 const char *pmg_last_error_string(void);
+/* 1 if the library is emitting ROCTx ranges named like the reference's log events "MulticolSOR" / "VecSetRandN"
+   (src/parmgmc.c:118-127): the marker library is in the process (rocprofv3 --marker-trace) or PMG_TRACE=1 */
+int pmg_trace_enabled(void);
 /* Library version "major.minor.patch" and the GPU architecture it was compiled for ("gfx950"). */
 const char *pmg_version(void);
 const char *pmg_gpu_arch(void);

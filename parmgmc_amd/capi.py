@@ -72,6 +72,7 @@ _vp, _i32, _i64, _u64, _dbl, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 _sig = {
     "pmg_last_error_string": (C.c_char_p, []),
     "pmg_version": (C.c_char_p, []),
+    "pmg_trace_enabled": (_int, []),
     "pmg_gpu_arch": (C.c_char_p, []),
     "pmg_mcsor_create_csr": (_int, [_i32, _vp, _vp, _vp, C.POINTER(_vp)]),
     "pmg_mcsor_create_csr_idx": (_int, [_i64, _vp, _vp, _vp, _int, C.POINTER(_vp)]),

@@ -1,5 +1,6 @@
 /* Error reporting, version strings and device-memory helpers of libparmgmc_hip. */
 #include "pmg_internal.h"
+#include <dlfcn.h>
 #include <stdarg.h>
 
 static _Thread_local char pmg_errbuf[512] = "";
@@ -46,7 +47,10 @@ pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t
 {
   PMG_CHECK(n >= 0, PMG_ERR_ARG_OUTOFRANGE, "negative length %lld", (long long)n);
   PMG_CHECK(x_dev || n == 0, PMG_ERR_ARG_NULL, "null vector");
-  PMG_KERNEL(pmgk_fill_normal_rows(n, seed, counter, x_dev, stream));
+  pmg_trace_begin(PMG_EVENT_VEC_SET_RANDOM_NORMAL);
+  const int rc = pmgk_fill_normal_rows(n, seed, counter, x_dev, stream);
+  pmg_trace_end();
+  PMG_KERNEL(rc);
   return PMG_SUCCESS;
 }
 
@@ -95,4 +99,53 @@ pmg_status pmg_narrow_csr(int64_t nrows, int64_t ncols, const void *rowptr, cons
   *rp = *rp_own = a;
   *ci = *ci_own = b;
   return PMG_SUCCESS;
+}
+
+/* ---- trace ranges ------------------------------------------------------------------------------------------------
+   The reference brackets its two hot functions with PETSc log events "MulticolSOR" (src/mc_sor.c:221,237) and
+   "VecSetRandN" (src/parmgmc.c:75,114), registered in ParMGMCInitialize (src/parmgmc.c:118-127).  Here the same
+   names are ROCTx ranges, so `rocprofv3 --marker-trace` shows them on the host time line next to the kernels.  The
+   marker library is used only when it is already in the process (the profiler loaded it) or PMG_TRACE=1 asks for it;
+   otherwise a range costs one predictable branch. */
+typedef int (*pmg_roctx_push_fn)(const char *);
+typedef int (*pmg_roctx_pop_fn)(void);
+static pmg_roctx_push_fn pmg_roctx_push;
+static pmg_roctx_pop_fn  pmg_roctx_pop;
+static int               pmg_trace_state; /* 0 = not probed, 1 = on, 2 = off */
+
+static void pmg_trace_probe(void)
+{
+  static const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+  const char        *env     = getenv("PMG_TRACE");
+  const int          force   = env && env[0] == '1';
+  pmg_trace_state            = 2;
+  if (env && env[0] == '0') return;
+  for (unsigned q = 0; q < sizeof names / sizeof names[0]; ++q) {
+    void *h = dlopen(names[q], RTLD_LAZY | (force ? 0 : RTLD_NOLOAD));
+    if (!h) continue;
+    pmg_roctx_push = (pmg_roctx_push_fn)dlsym(h, "roctxRangePushA");
+    pmg_roctx_pop  = (pmg_roctx_pop_fn)dlsym(h, "roctxRangePop");
+    if (pmg_roctx_push && pmg_roctx_pop) {
+      pmg_trace_state = 1;
+      return;
+    }
+  }
+}
+
+void pmg_trace_begin(const char *name)
+{
+  if (pmg_trace_state == 0) pmg_trace_probe();
+  if (pmg_trace_state == 1) (void)pmg_roctx_push(name);
+}
+
+void pmg_trace_end(void)
+{
+  if (pmg_trace_state == 1) (void)pmg_roctx_pop();
+}
+
+/* 1 if ranges are being emitted (diagnostic for the tests) */
+int pmg_trace_enabled(void)
+{
+  if (pmg_trace_state == 0) pmg_trace_probe();
+  return pmg_trace_state == 1;
 }

@@ -178,8 +178,11 @@ static pmg_status pmg_grid_one_sweep(pmg_grid g, int dir, int noisy, int scaled,
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, noisy, scaled, seed, sweep);
   const int c0 = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, 1, NULL, b, y, stream));
-  PMG_KERNEL(pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, 1, NULL, b, y, stream));
+  pmg_trace_begin(PMG_EVENT_MULTICOL_SOR); /* PetscLogEventBegin(MULTICOL_SOR), src/mc_sor.c:221 */
+  int rc = pmgk_grid_color_sweep(&g->L, &op, c0, 0, g->L.nz, 1, NULL, b, y, stream);
+  if (!rc) rc = pmgk_grid_color_sweep(&g->L, &op, 1 - c0, 0, g->L.nz, 1, NULL, b, y, stream);
+  pmg_trace_end();
+  PMG_KERNEL(rc);
   if (g->lrc && noisy) PMG_CALL(pmg_lrc_rhs_done(g->lrc, stream));
   if (g->lrc) PMG_CALL(pmg_lrc_post(g->lrc, dir, y, stream));
   return PMG_SUCCESS;

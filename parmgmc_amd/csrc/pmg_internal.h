@@ -62,6 +62,11 @@ pmg_status pmg_parsor_build_dataflow(int32_t n, const int32_t *rowptr, const int
 int        pmg_invert_small(int k, double *a_colmajor, double *inv); /* Gauss-Jordan, partial pivoting; a is overwritten; nonzero = singular */
 
 pmg_status pmg_narrow_csr(int64_t nrows, int64_t ncols, const void *rowptr, const void *colidx, int idx_width, const int32_t **rp, const int32_t **ci, int32_t **rp_own, int32_t **ci_own);
+/* trace ranges named like the reference's PetscLogEvents (src/parmgmc.c:118-127) */
+#define PMG_EVENT_MULTICOL_SOR "MulticolSOR"
+#define PMG_EVENT_VEC_SET_RANDOM_NORMAL "VecSetRandN"
+void pmg_trace_begin(const char *name);
+void pmg_trace_end(void);
 /* device allocation helpers (zero-filled) */
 pmg_status pmg_dev_alloc(void **p, size_t bytes);
 pmg_status pmg_dev_upload(void **p, const void *host, size_t bytes);

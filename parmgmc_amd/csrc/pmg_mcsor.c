@@ -395,11 +395,15 @@ static pmg_status mcsor_one_sweep(pmg_mcsor mc, int dir, int noisy, int scaled, 
 {
   pmgk_sell S = mc->S;
   S.sqrtdiag  = scaled ? mc->sqrtd_scaled_dev : mc->sqrtd_dev;
+  int rc      = 0;
+  pmg_trace_begin(PMG_EVENT_MULTICOL_SOR); /* PetscLogEventBegin(MULTICOL_SOR), src/mc_sor.c:221 */
   if (dir == PMG_SOR_FORWARD_SWEEP) {
-    for (int32_t c = 0; c < mc->ncolors; ++c) PMG_KERNEL(pmgk_sell_color_sweep(&S, mc->cslice[c], mc->cslice[c + 1] - mc->cslice[c], mc->omega, noisy, seed, sweep, b_p, y_p, stream));
+    for (int32_t c = 0; c < mc->ncolors && !rc; ++c) rc = pmgk_sell_color_sweep(&S, mc->cslice[c], mc->cslice[c + 1] - mc->cslice[c], mc->omega, noisy, seed, sweep, b_p, y_p, stream);
   } else {
-    for (int32_t c = mc->ncolors - 1; c >= 0; --c) PMG_KERNEL(pmgk_sell_color_sweep(&S, mc->cslice[c], mc->cslice[c + 1] - mc->cslice[c], mc->omega, noisy, seed, sweep, b_p, y_p, stream));
+    for (int32_t c = mc->ncolors - 1; c >= 0 && !rc; --c) rc = pmgk_sell_color_sweep(&S, mc->cslice[c], mc->cslice[c + 1] - mc->cslice[c], mc->omega, noisy, seed, sweep, b_p, y_p, stream);
   }
+  pmg_trace_end();
+  PMG_KERNEL(rc);
   return PMG_SUCCESS;
 }
 

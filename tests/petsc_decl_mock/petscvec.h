@@ -1,0 +1,1 @@
+#include "petsc_decl_mock.h"

@@ -110,3 +110,14 @@ def test_idx_width_entry_points_check_their_arguments():
     prp, pci, pv = np.array([0, 1, 2, 3], np.int64), np.array([0, 0, 7], np.int64), np.ones(3)
     assert lib.pmg_mgmc_set_level_interpolation_idx(mg, 1, 3, 1, prp.ctypes.data, pci.ctypes.data, pv.ctypes.data, 64) == 63  # column 7 of 1
     assert lib.pmg_mgmc_destroy(C.byref(mg)) == 0
+
+
+def test_trace_ranges_can_be_switched():
+    """ROCTx ranges named like the reference's log events (src/parmgmc.c:118-127): on with PMG_TRACE=1, off with 0"""
+    import os
+    import sys
+
+    code = "import ctypes; L = ctypes.CDLL(%r); print(L.pmg_trace_enabled())" % str(capi.library_path())
+    for env, want in (("1", "1"), ("0", "0")):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PMG_TRACE=env))
+        assert out.stdout.strip() == want, (env, out.stdout, out.stderr)
