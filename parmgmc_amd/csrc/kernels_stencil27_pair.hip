@@ -1,0 +1,377 @@
+// Phase-fused, paired class-stencil Gibbs/SOR sweep for the coarse levels of a DMDA hierarchy (gfx950).
+//
+// Same operation and the same bits as st27_color_sweep_kernel (kernels_stencil27.hip): MCSORApply_SEQAIJ (reference
+// src/mc_sor.c:241-296) + PrepareRHS (src/pc_mcgibbs.c:119-128) on a 27-point Galerkin operator under the 8-colour
+// parity colouring, vectors in natural order.  What changes is how the work is cut:
+//
+//   * OUT OF PLACE.  A sweep reads the vector `y_in` and writes `y_out` (the caller swaps the two afterwards).  With
+//     old and new values in different buffers there is no read-after-write hazard BETWEEN workgroups, which is what
+//     forces the in-place kernel to one launch per colour.
+//   * ONE LAUNCH PER z-PARITY PHASE instead of four: the planes of one z-parity are independent of each other during
+//     a phase (their 18 out-of-plane neighbours have the other parity).  Inside a plane the four colours (px, py)
+//     depend on each other; a workgroup resolves that for a tile of lines by itself:
+//       - a thread owns the PAIR of points x0 = 2p, x1 = 2p + 1 of a line, i.e. one point of each x-parity.  The second
+//         of them needs the first one's new value at x0 / x0 + 2 (forward) -- its own register and its neighbour
+//         lane's, one wave shuffle;
+//       - stage A sweeps the lines of the first y-parity of the tile (T + 1 of them, one per wavefront), leaves the new
+//         values in LDS, and stage B, behind ONE workgroup barrier, sweeps the T lines in between, reading the new
+//         values of the lines above and below from LDS;
+//       - whatever a tile needs from beyond its edges it recomputes: three pairs of the 64 of a wavefront and one of
+//         the T + 1 first-stage lines are redundant.  Counter-based noise and a fixed arithmetic order make the
+//         recomputed values identical to the ones the owning tile stores, so only owners store.
+//   * DENSE LOADS.  The 27 neighbours of the two points lie on 9 lines; each is fetched as one 16-byte load (x0, x1)
+//     plus the two values beside it, consecutive lanes reading consecutive addresses.  The per-colour kernel issues 54
+//     stride-2 loads for the same two points and uses half of every cache line it touches.
+//
+// Arithmetic order per point is unchanged (sum starts at w, neighbours subtracted in ascending natural index, absent
+// ones entering with a zero table coefficient at a valid address), the file is compiled with -ffp-contract=off, so
+// results are bit-identical to the per-colour kernel and to the sliced-ELL sweep of the assembled matrix.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "pmg_kernels.h"
+#include "pmg_rng.hpp"
+
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8))); // natural-order lines of odd length start 8-byte aligned
+
+constexpr int PT    = 4;  // line pairs per tile: T + 1 = 5 wavefronts per workgroup
+constexpr int VALID = 60; // pairs per wavefront whose results are final (2 + 2 halo pairs)
+constexpr int HL    = 2;  // halo pairs on the left
+
+__device__ __forceinline__ int pos_class(int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 2 : 1); }
+
+// Lane i receives lane i-1's (from_prev) / lane i+1's (from_next) value: DPP full-wavefront shifts of GFX9
+// (wave_shr:1 = 0x138, wave_shl:1 = 0x130), two v_mov_b32 per double, no LDS crossbar.  Lane 0 of from_prev and lane 63 of
+// from_next receive 0: only the outermost halo lanes use them and nothing final depends on those lanes.
+__device__ __forceinline__ double from_prev(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (block id mod 8), each with its own L2.  With
+// the plain (x, y, z) order every L2 ends up fetching more than half of every plane (a tile reads the lines around it
+// in three planes, and the tiles of a plane are spread over all XCDs: 4.5 x the vector in total, rocprofv3 FETCH_SIZE).
+// Here the (line tile, plane) items are numbered plane after plane and XCD x takes the x-th eighth of that list, walking
+// through it in order: an L2 fetches its own planes once (plus one seam plane per neighbour), the planes k-1 / k+1 of one
+// tile are the L2-resident neighbours of the next, and the shares differ by at most one tile (bands of line tiles of a
+// 2^k+1 grid cannot be balanced: 33 tiles over 8 XCDs leave one XCD with 5 and the others with 4).
+// Placement only: no result depends on it.  Returns false for the padding blocks.
+__device__ __forceinline__ bool xcd_block(int nbx, int nby, int nbz, int &bx, int &by, int &bz)
+{
+  const int     bid = (int)blockIdx.x, xcd = bid & 7, q = bid >> 3; // q: index inside this XCD's share
+  const int64_t T   = (int64_t)nby * nbz;
+  const int     lo = (int)(xcd * T / 8), hi = (int)((xcd + 1) * T / 8);
+  bx               = q % nbx;
+  const int t      = lo + q / nbx;
+  by               = t % nby;
+  bz               = t / nby;
+  return t < hi;
+}
+static inline unsigned xcd_grid(int nbx, int nby, int nbz)
+{
+  const int64_t T = (int64_t)nby * nbz;
+  return (unsigned)(8 * nbx * ((T + 7) / 8));
+}
+
+struct pair_ctx {
+  int      nx, ny, nzg;
+  int      x0, j, k;
+  int      xu; // 2 p without the clamp of the halo lanes outside the domain: the noise counter of a halo pair must be the
+               // one of ITS position, because its sin branch is handed to the next lane
+  bool     act0, act1;
+  int64_t  line; // natural index of x = 0 on this line: nx (j + ny k)
+  uint32_t key0, key1;
+  uint64_t sweep;
+  double   om1;
+};
+
+// New values of the two points of a pair.  FIRST1: the point x1 is swept before x0 (backward order).
+// get_row(row, r) delivers row `row` = 3 (dz+1) + (dy+1) of the neighbourhood as r = y at x0-1, x0, x1, x1+1, holding the
+// values the FIRST point sees.  The rows are consumed as a stream, in the order of the sum: the first point takes all
+// of them; the second point's terms of the rows before its own line (0..3) are accumulated in the same pass, its own
+// line (row 4) needs the first colour's new values on both sides -- own register and the neighbouring lane's, one
+// wave shuffle -- and the rows behind it (5..8) are kept (12 values) until then.  Keeping all 36 values of the
+// neighbourhood instead costs 130 VGPRs and two fifths of the occupancy.
+template <bool NOISY, bool FIRST1, class RowFn>
+__device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, const double *s_coef, const double *s_idiag, const double *s_sqrtd, const pmg::LogTabEntry *s_logtab, d2 bb)
+{
+  constexpr int F = FIRST1 ? 1 : 0, S = 1 - F;
+  const int     cyz   = 3 * pos_class(C.j, C.ny) + 9 * pos_class(C.k, C.nzg);
+  const int     cls0  = pos_class(C.x0, C.nx) + cyz, cls1 = pos_class(C.x0 + 1, C.nx) + cyz;
+  const int     clsF  = F ? cls1 : cls0, clsS = S ? cls1 : cls0;
+  double        w0 = bb.x, w1 = bb.y;
+  if (NOISY) {
+    // noise = row stream of the natural index r: counter r >> 1, branch r & 1.  x0 is even, so whether the pair shares
+    // one Box-Muller draw depends on the line alone (wave-uniform)
+    const int64_t r0 = C.line + C.xu;
+    double        z0, z1;
+    if (__builtin_amdgcn_readfirstlane((int)(C.line & 1)) == 0) {
+      pmg::normal_pair((uint32_t)((uint64_t)r0 >> 1), 0u, (uint32_t)C.sweep, (uint32_t)(C.sweep >> 32), C.key0, C.key1, s_logtab, z0, z1);
+    } else {
+      // r0 is odd: the draw of counter (r0 + 1) >> 1 serves x1 (cos branch) and the NEXT pair's x0 (sin branch), so
+      // every thread still makes one draw and receives its x0 value from the lane before it
+      double zs;
+      pmg::normal_pair((uint32_t)((uint64_t)(r0 + 1) >> 1), 0u, (uint32_t)C.sweep, (uint32_t)(C.sweep >> 32), C.key0, C.key1, s_logtab, z1, zs);
+      z0 = from_prev(zs);
+    }
+    w0 = z0 * s_sqrtd[cls0] + w0;
+    w1 = z1 * s_sqrtd[cls1] + w1;
+  }
+  const double *cfF = s_coef + 27 * clsF, *cfS = s_coef + 27 * clsS;
+  double        accF = F ? w1 : w0, accS = S ? w1 : w0;
+  double        oldF = 0.0, oldS = 0.0, keep[4][3];
+#pragma unroll
+  for (int row = 0; row < 9; ++row) {
+    double r[4];
+    get_row(row, r);
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int e = 3 * row + dx + 1;
+      if (e != 13) accF = accF - cfF[e] * r[1 + F + dx];
+    }
+    if (row < 4) {
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) accS = accS - cfS[3 * row + dx + 1] * r[1 + S + dx];
+    } else if (row == 4) {
+      oldF = r[1 + F];
+      oldS = r[1 + S];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) keep[row - 5][q] = r[S + q];
+    }
+  }
+  double nF = C.om1 * oldF + s_idiag[clsF] * accF;
+  nF        = (F ? C.act1 : C.act0) ? nF : 0.0;
+  // the second point's neighbours on its own line: FIRST1 = false: x0 (own) and the next pair's x0; true: the previous
+  // pair's x1 and x1 (own)
+  const double nb = FIRST1 ? from_prev(nF) : from_next(nF);
+  accS            = accS - cfS[12] * (FIRST1 ? nb : nF);
+  accS            = accS - cfS[14] * (FIRST1 ? nF : nb);
+#pragma unroll
+  for (int row = 5; row < 9; ++row)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) accS = accS - cfS[3 * row + dx + 1] * keep[row - 5][dx + 1];
+  double nS = C.om1 * oldS + s_idiag[clsS] * accS;
+  nS        = (S ? C.act1 : C.act0) ? nS : 0.0;
+  const d2 out = {F ? nS : nF, F ? nF : nS};
+  return out;
+}
+
+// one row of the neighbourhood from a vector in natural order behind one ghost plane; an absent line / plane is
+// replaced by the centre line (finite values that meet a zero coefficient)
+__device__ __forceinline__ void load_row(double (&r)[4], const double *vec, int nx, int ny, int xc0, int jj, int kk)
+{
+  const double *row = vec + (int64_t)nx * (jj + (int64_t)ny * (kk + 1));
+  const d2u     v   = *reinterpret_cast<const d2u *>(row + xc0);
+  r[0]              = from_prev(v.y); // y at x0 - 1 = the previous pair's x1: one 16-byte load per row and lane, the two
+  r[1]              = v.x;            // values beside the pair come from the neighbouring lanes
+  r[2]              = v.y;
+  r[3]              = from_next(v.x);
+}
+
+// `kfirst`, `kfirst + 2`, ...: the planes of this phase.  y_other: the vector that holds the CURRENT values of the
+// planes of the other z-parity (y_in in the first phase of a sweep, y_out in the second).
+#ifndef PMG_ST27_PAIR_WAVES
+#define PMG_ST27_PAIR_WAVES 5
+#endif
+template <bool NOISY, bool BACKWARD>
+__global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(PMG_ST27_PAIR_WAVES, 8))) void st27_pair_phase_kernel(pmgk_st27 S, int nbx, int nby, int nbz, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, const double *y_in, double *y_out, const double *y_other)
+{
+  __shared__ double           s_coef[27 * 27], s_idiag[27], s_sqrtd[27];
+  __shared__ pmg::LogTabEntry s_logtab[NOISY ? PMG_LOGTAB_SIZE : 1];
+  __shared__ d2               s_new[PT + 1][64];
+  const int                   lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int                   tid  = lane + 64 * w;
+  for (int q = tid; q < 27 * 27; q += 64 * (PT + 1)) s_coef[q] = S.coef[q]; // (padding blocks of the last band leave below, before the barrier)
+  if (tid < 27) {
+    s_idiag[tid] = S.idiag[tid];
+    s_sqrtd[tid] = S.sqrtdiag[tid];
+  }
+  int bx, by, bz;
+  if (!xcd_block(nbx, nby, nbz, bx, by, bz)) return; // whole workgroup: before any barrier
+  if (NOISY) pmg::load_log_table(s_logtab);
+  __syncthreads();
+
+  const int nx = S.nx, ny = S.ny;
+  const int npairs = (nx + 1) / 2;
+  const int p      = VALID * bx - HL + lane;
+  const int pc     = min(max(p, 0), npairs - 1); // inactive lanes work on a valid pair and publish zeros
+  pair_ctx  C;
+  C.nx   = nx;
+  C.ny   = ny;
+  C.nzg  = S.nzg;
+  C.x0   = 2 * pc;
+  C.xu   = 2 * p;
+  C.k    = kfirst + 2 * bz;
+  C.act0 = p >= 0 && p < npairs;
+  C.act1 = C.act0 && C.x0 + 1 < nx;
+  C.key0 = key0;
+  C.key1 = key1;
+  C.sweep = sweep;
+  C.om1   = one_minus_omega;
+  const int  xc0 = C.x0;
+  const bool final_lane = lane >= HL && lane < HL + VALID; // lanes whose results are complete at the end of each stage
+  const int  jt = 2 * PT * by;
+  const bool hasD = C.k > 0, hasU = C.k < S.nzg - 1;
+
+  // ---- stage A: the lines of the y-parity that is swept first --------------------------------------------------------
+  {
+    const int jA = BACKWARD ? jt - 1 + 2 * w : jt + 2 * w;
+    d2        nw = {0.0, 0.0};
+    if (jA >= 0 && jA < ny) {
+      C.j    = jA;
+      C.line = (int64_t)nx * (jA + (int64_t)ny * C.k);
+      const int jS = jA > 0 ? jA - 1 : jA, jN = jA < ny - 1 ? jA + 1 : jA;
+      const int64_t lrow = (int64_t)nx * (jA + (int64_t)ny * (C.k + 1)) + xc0;
+      const d2u     bv   = *reinterpret_cast<const d2u *>(b + lrow);
+      const d2      bb   = {bv.x, bv.y};
+      auto          rows = [&](int row, double (&r)[4]) {
+        const int dz = row / 3 - 1, dy = row % 3 - 1;
+        const bool okz = dz < 0 ? hasD : (dz > 0 ? hasU : true);
+        load_row(r, (dz != 0 && okz) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jA), okz ? C.k + dz : C.k);
+      };
+      nw = sweep_pair<NOISY, BACKWARD>(C, rows, s_coef, s_idiag, s_sqrtd, s_logtab, bb);
+      const bool owned   = BACKWARD ? w >= 1 : w < PT; // the other first-stage line belongs to the neighbouring tile
+      if (owned && final_lane && C.act0) {
+        if (C.act1) *reinterpret_cast<d2u *>(y_out + lrow) = d2u{nw.x, nw.y};
+        else y_out[lrow] = nw.x;
+      }
+    }
+    s_new[w][lane] = nw;
+  }
+  __syncthreads();
+  // ---- stage B: the lines in between, whose in-plane neighbours above and below are the new values in LDS ------------
+  if (w < PT) {
+    const int jB = BACKWARD ? jt + 2 * w : jt + 2 * w + 1;
+    if (jB < ny) {
+      C.j    = jB;
+      C.line = (int64_t)nx * (jB + (int64_t)ny * C.k);
+      const int jS = jB > 0 ? jB - 1 : jB, jN = jB < ny - 1 ? jB + 1 : jB;
+      const int64_t lrow = (int64_t)nx * (jB + (int64_t)ny * (C.k + 1)) + xc0;
+      const d2u     bv   = *reinterpret_cast<const d2u *>(b + lrow);
+      const d2      bb   = {bv.x, bv.y};
+      auto          rows = [&](int row, double (&r)[4]) {
+        const int dz = row / 3 - 1, dy = row % 3 - 1;
+        if (dz == 0 && dy != 0) { // the lines above / below in this plane: new values of stage A
+          const int q = dy < 0 ? w : w + 1;
+          const d2  c = s_new[q][lane];
+          r[0]        = from_prev(c.y);
+          r[1]        = c.x;
+          r[2]        = c.y;
+          r[3]        = from_next(c.x);
+          return;
+        }
+        const bool okz = dz < 0 ? hasD : (dz > 0 ? hasU : true);
+        load_row(r, (dz != 0 && okz) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jB), okz ? C.k + dz : C.k);
+      };
+      const d2 nw = sweep_pair<NOISY, BACKWARD>(C, rows, s_coef, s_idiag, s_sqrtd, s_logtab, bb);
+      if (final_lane && C.act0) {
+        if (C.act1) *reinterpret_cast<d2u *>(y_out + lrow) = d2u{nw.x, nw.y};
+        else y_out[lrow] = nw.x;
+      }
+    }
+  }
+}
+
+// r = b - A y with the pair mapping (dense loads); the diagonal term is added last, like st27_residual_kernel
+__global__ __launch_bounds__(256) void st27_pair_residual_kernel(pmgk_st27 S, int nbx, int nby, int nbz, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+{
+  __shared__ double s_coef[27 * 27];
+  const int         tid = threadIdx.x + 64 * threadIdx.y;
+  int bx, by, bz;
+  if (!xcd_block(nbx, nby, nbz, bx, by, bz)) return;
+  for (int q = tid; q < 27 * 27; q += 256) s_coef[q] = S.coef[q];
+  __syncthreads();
+  const int nx = S.nx, ny = S.ny;
+  // lanes 0 and 63 only supply their neighbours with the values beside the pairs: 62 pairs per wavefront
+  const int npairs = (nx + 1) / 2;
+  const int p = 62 * bx - 1 + (int)threadIdx.x, j = 4 * by + __builtin_amdgcn_readfirstlane(threadIdx.y), k = bz;
+  if (j >= ny) return; // wave-uniform
+  const int  x0   = 2 * min(max(p, 0), npairs - 1);
+  const bool act0 = p >= 0 && p < npairs && threadIdx.x >= 1 && threadIdx.x <= 62, act1 = act0 && x0 + 1 < nx;
+  const int  jS = j > 0 ? j - 1 : j, jN = j < ny - 1 ? j + 1 : j, kD = k > 0 ? k - 1 : k, kU = k < S.nzg - 1 ? k + 1 : k;
+  const int     cyz  = 3 * pos_class(j, ny) + 9 * pos_class(k, S.nzg);
+  const double *cf0 = s_coef + 27 * (pos_class(x0, nx) + cyz), *cf1 = s_coef + 27 * (pos_class(x0 + 1, nx) + cyz);
+  // the per-colour kernel ADDS the products one by one starting from 0 and the diagonal term last: same order here
+  double s0 = 0.0, s1 = 0.0, c0 = 0.0, c1 = 0.0;
+#pragma unroll
+  for (int row = 0; row < 9; ++row) {
+    const int dz = row / 3 - 1, dy = row % 3 - 1;
+    double    r4[4];
+    load_row(r4, y, nx, ny, x0, dy < 0 ? jS : (dy > 0 ? jN : j), dz < 0 ? kD : (dz > 0 ? kU : k));
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int e = 3 * row + dx + 1;
+      if (e == 13) continue;
+      s0 = s0 + cf0[e] * r4[1 + dx];
+      s1 = s1 + cf1[e] * r4[2 + dx];
+    }
+    if (row == 4) {
+      c0 = r4[1];
+      c1 = r4[2];
+    }
+  }
+  s0 = s0 + cf0[13] * c0;
+  s1 = s1 + cf1[13] * c1;
+  const int64_t lrow = (int64_t)nx * (j + (int64_t)ny * (k + 1)) + x0;
+  const d2u     bv   = *reinterpret_cast<const d2u *>(b + lrow);
+  if (act1) *reinterpret_cast<d2u *>(r + lrow) = d2u{bv.x - s0, bv.y - s1};
+  else if (act0) r[lrow] = bv.x - s0;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
+
+template <bool NOISY, bool BACKWARD>
+void launch_phase(const pmgk_st27 &S, int pz, double om1, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, const double *y_other, hipStream_t s)
+{
+  const int cz = (S.nzg - pz + 1) / 2; // planes of this parity
+  if (cz <= 0) return;
+  const int  npairs = (S.nx + 1) / 2;
+  const int  nbx = (npairs + VALID - 1) / VALID, nby = (S.ny + 2 * PT - 1) / (2 * PT);
+  const dim3 grid(xcd_grid(nbx, nby, cz)), block(64, PT + 1);
+  hipLaunchKernelGGL((st27_pair_phase_kernel<NOISY, BACKWARD>), grid, block, 0, s, S, nbx, nby, cz, pz, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y_in, y_out, y_other);
+}
+
+} // namespace
+
+// One directional sweep OUT OF PLACE: y_out <- sweep(b, y_in); y_in is left untouched, the two must not overlap.
+// Single-device levels only (all planes owned: kz0 = 0, nz = nzg).
+extern "C" int pmgk_st27_sweep_pp(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, void *stream)
+{
+  if (S->kz0 != 0 || S->nz != S->nzg || y_in == y_out) return 1;
+  const double om1 = 1. - omega;
+  hipStream_t  s   = (hipStream_t)stream;
+  for (int phase = 0; phase < 2; ++phase) {
+    const int     pz    = backward ? 1 - phase : phase;
+    const double *other = phase == 0 ? y_in : y_out;
+    if (noisy) {
+      if (backward) launch_phase<true, true>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s);
+      else launch_phase<true, false>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s);
+    } else {
+      if (backward) launch_phase<false, true>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s);
+      else launch_phase<false, false>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s);
+    }
+  }
+  return launch_status();
+}
+
+extern "C" int pmgk_st27_residual_pair(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream)
+{
+  if (S->kz0 != 0 || S->nz != S->nzg) return 1;
+  if (S->nz <= 0) return 0;
+  const int  npairs = (S->nx + 1) / 2;
+  const int  nbx = (npairs + 61) / 62, nby = (S->ny + 3) / 4;
+  const dim3 grid(xcd_grid(nbx, nby, S->nz)), block(64, 4);
+  hipLaunchKernelGGL(st27_pair_residual_kernel, grid, block, 0, (hipStream_t)stream, *S, nbx, nby, S->nz, b, y, r);
+  return launch_status();
+}

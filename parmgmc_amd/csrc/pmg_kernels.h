@@ -111,6 +111,11 @@ typedef struct {
 int pmgk_st27_sweep(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream);
 int pmgk_st27_sweep_phase(const pmgk_st27 *S, int backward, int phase, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream);
 int pmgk_st27_residual(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream);
+/* single-device levels (kz0 = 0, nz = nzg), kernels_stencil27_pair.hip: one directional sweep OUT OF PLACE (y_out <- sweep(b,
+   y_in), two launches: one per z-parity phase, the four in-plane colours fused) and the residual with dense paired loads;
+   same bits as the per-colour kernels */
+int pmgk_st27_sweep_pp(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, void *stream);
+int pmgk_st27_residual_pair(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream);
 int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims *C, const double *r, double *bc, void *stream);
 /* fine planes kbegin .. kbegin+kcount-1 (global indices; may include the in-domain ghost planes of a slab) */
 int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_dims *C, int kbegin, int kcount, const double *ec, double *x, void *stream);

@@ -42,6 +42,7 @@ typedef struct {
   pmg_mcsor mc;
   int64_t   ld;
   double   *b, *x, *r;
+  double   *x2; /* second buffer of the out-of-place class-stencil sweep (single-device levels): x and x2 swap after every directional sweep */
   /* transfers to the next coarser level, in layout numbering on the device */
   int32_t  P_nrows, R_nrows;
   int32_t *cpos_dev; /* grid level only: layout position of every point of the next coarser level */
@@ -495,6 +496,33 @@ pmg_status pmg_mgmc_set_keep_host(pmg_mgmc h, int keep)
   return PMG_SUCCESS;
 }
 
+/* the phase-fused out-of-place sweep and the paired residual (kernels_stencil27_pair.hip) serve class-stencil levels
+   that live on one device; PMG_ST27_PAIR=0 keeps the one-launch-per-colour kernels (same bits) */
+static int st27_use_pair(const mg_level *Lv)
+{
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("PMG_ST27_PAIR");
+    env           = e ? atoi(e) : 1;
+  }
+  return env && Lv->is_st27 && !Lv->distributed && Lv->kz0 == 0 && Lv->nzl == Lv->nz;
+}
+
+/* one directional sweep of a class-stencil level on (b, *x): in place, or out of place into Lv->x2 followed by a swap of
+   the two buffers when x is the level's own iterate */
+static pmg_status st27_one_sweep(mg_level *Lv, const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, void *stream)
+{
+  if (Lv->x2 && st27_use_pair(Lv)) {
+    PMG_KERNEL(pmgk_st27_sweep_pp(S, backward, omega, noisy, seed, sweep, b, Lv->x, Lv->x2, stream));
+    double *t = Lv->x;
+    Lv->x     = Lv->x2;
+    Lv->x2    = t;
+    return PMG_SUCCESS;
+  }
+  PMG_KERNEL(pmgk_st27_sweep(S, backward, omega, noisy, seed, sweep, b, Lv->x, stream));
+  return PMG_SUCCESS;
+}
+
 static void level_set_padded(mg_level *Lv)
 {
   Lv->padded = 1;
@@ -843,6 +871,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
     PMG_CALL(pmg_dev_alloc((void **)&Lv->b, sizeof(double) * (size_t)Lv->ld));
     PMG_CALL(pmg_dev_alloc((void **)&Lv->x, sizeof(double) * (size_t)Lv->ld));
     PMG_CALL(pmg_dev_alloc((void **)&Lv->r, sizeof(double) * (size_t)Lv->ld));
+    if (st27_use_pair(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld));
   }
   free(pos);
   PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)F->ld));
@@ -1168,6 +1197,7 @@ static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
     PMG_HIP(hipMemset(Lv->b, 0, sizeof(double) * (size_t)Lv->ld));
     PMG_HIP(hipMemset(Lv->x, 0, sizeof(double) * (size_t)Lv->ld));
     PMG_HIP(hipMemset(Lv->r, 0, sizeof(double) * (size_t)Lv->ld));
+    if (st27_use_pair(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld)); /* zero-filled: the ghost planes stay zero */
   }
   PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)F->ld));
   PMG_CALL(pmg_dev_alloc((void **)&h->b_lay, sizeof(double) * (size_t)F->ld));
@@ -1225,7 +1255,7 @@ static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, 
         PMG_KERNEL(pmgk_st27_sweep_phase(&S, backward, 1, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
         PMG_CALL(halo_level(h, Lv, Lv->x, stream));
       } else {
-        PMG_KERNEL(pmgk_st27_sweep(&S, backward, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
+        PMG_CALL(st27_one_sweep(Lv, &S, backward, h->omega, 1, seed, (*ctr)++, rhs, stream));
       }
       if (Lv->lrc) PMG_CALL(pmg_lrc_rhs_done(Lv->lrc, stream));
       if (Lv->lrc) PMG_CALL(pmg_lrc_post(Lv->lrc, backward ? PMG_SOR_BACKWARD_SWEEP : PMG_SOR_FORWARD_SWEEP, Lv->x, stream)); /* src/mc_sor.c:101-112 */
@@ -1334,7 +1364,8 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
     else if (Lv->is_st27) {
-      PMG_KERNEL(pmgk_st27_residual(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
+      if (st27_use_pair(Lv)) PMG_KERNEL(pmgk_st27_residual_pair(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
+      else PMG_KERNEL(pmgk_st27_residual(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
       if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* PCMGSetResidual(..., As[l]), src/pc_gamgmc.c:194 */
     }
     else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
@@ -1463,6 +1494,11 @@ pmg_status pmg_mgmc_level_sweep(pmg_mgmc h, int32_t level, int backward, int noi
   PMG_CHECK(Lv->is_st27, PMG_ERR_SUP, "level %d: only class-stencil levels (use pmg_grid_* / pmg_mcsor_* for the others)", level);
   pmgk_st27 S = Lv->st;
   S.sqrtdiag  = h->scaled ? Lv->st_sqrtd_scaled : Lv->st_sqrtd;
+  if (Lv->x2 && st27_use_pair(Lv)) { /* the production kernel: out of place into the level's second buffer, then copied back */
+    PMG_KERNEL(pmgk_st27_sweep_pp(&S, backward != 0, h->omega, noisy != 0, seed, counter, b_lvl, x_lvl, Lv->x2, stream));
+    PMG_HIP(hipMemcpyAsync(x_lvl, Lv->x2, sizeof(double) * (size_t)Lv->ld, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PMG_SUCCESS;
+  }
   PMG_KERNEL(pmgk_st27_sweep(&S, backward != 0, h->omega, noisy != 0, seed, counter, b_lvl, x_lvl, stream));
   return PMG_SUCCESS;
 }
@@ -1474,7 +1510,8 @@ pmg_status pmg_mgmc_level_residual(pmg_mgmc h, int32_t level, const double *b_lv
   PMG_CHECK(b_lvl && x_lvl && r_lvl, PMG_ERR_ARG_NULL, "null vector");
   if (Lv->is_grid) return pmg_grid_residual_cvec(Lv->g, b_lvl, x_lvl, r_lvl, stream);
   if (Lv->is_st27) {
-    PMG_KERNEL(pmgk_st27_residual(&Lv->st, b_lvl, x_lvl, r_lvl, stream));
+    if (st27_use_pair(Lv)) PMG_KERNEL(pmgk_st27_residual_pair(&Lv->st, b_lvl, x_lvl, r_lvl, stream));
+    else PMG_KERNEL(pmgk_st27_residual(&Lv->st, b_lvl, x_lvl, r_lvl, stream));
     return PMG_SUCCESS;
   }
   PMG_CHECK(Lv->mc, PMG_ERR_SUP, "level %d has no residual kernel", level);
@@ -1509,6 +1546,7 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
     pmg_dev_free(Lv->b);
     pmg_dev_free(Lv->x);
     pmg_dev_free(Lv->r);
+    pmg_dev_free(Lv->x2);
     pmg_dev_free(Lv->cpos_dev);
     pmg_dev_free(Lv->st_coef);
     pmg_dev_free(Lv->st_idiag);

@@ -10,7 +10,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from parmgmc_amd import MGMC  # noqa: E402
 
+only = os.environ.get("PMG_VC_ONLY")
 for n, levels, reps in ((257, 5, 20), (513, 6, 8)):
+    if only and int(only) != n:
+        continue
     mg = MGMC(n, n, n, 10.0, levels).setup()
     b = torch.ones(n ** 3, dtype=torch.float64, device="cuda")
     y = torch.zeros_like(b)
