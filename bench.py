@@ -128,7 +128,7 @@ def cpu_baseline(nsub: int = 512, nfull: int = 512, samples: int = 0) -> dict:
     return out
 
 
-def mgmc_secondary(n: int = 257, levels: int = 5, its: int = 20) -> dict:
+def mgmc_secondary(n: int = 257, levels: int = 5, its: int = 40) -> dict:
     """Secondary line (BASELINE config 1, "256^3 4-level V-cycle Gibbs, 1 MI355X", on the PETSc-coarsenable 257^3):
     samples/s of the Multigrid Monte Carlo chain (PCGAMGMC defaults: sorgibbs 1+1 sweeps per level, exact coarse
     sampler on 17^3).  Not the headline metric."""
@@ -141,7 +141,7 @@ def mgmc_secondary(n: int = 257, levels: int = 5, its: int = 20) -> dict:
     setup_s = time.perf_counter() - t0
     b = torch.ones(n ** 3, dtype=torch.float64, device="cuda")
     y = torch.zeros(n ** 3, dtype=torch.float64, device="cuda")
-    ctr = mg.sample(b, y, 3, seed=0xCAFE)
+    ctr = mg.sample(b, y, 10, seed=0xCAFE)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
