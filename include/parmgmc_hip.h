@@ -254,6 +254,28 @@ pmg_status pmg_chol_sample(pmg_chol ch, const double *b_dev, double *y_dev, int 
 pmg_status pmg_chol_destroy(pmg_chol *ch);
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* MCSOR on a general AIJ matrix distributed by row blocks: replaces MCSORApply_MPIAIJ (src/mc_sor.c:298-381)  */
+/* ------------------------------------------------------------------------------------------------------ */
+typedef struct pmg_distmcsor_s *pmg_distmcsor;
+/* One rank per device owns a contiguous block of rows (MatGetOwnershipRange).  `mc`: its local operator -- the rows with
+   the off-process COLUMNS appended as identity rows in one extra colour that is never swept (the diagonal / off-diagonal
+   blocks of MatMPIAIJGetSeqAIJ, src/mc_sor.c:308, merged into one CSR), created with pmg_mcsor_create_csr[_idx], a USER
+   colouring that is a valid distance-1 colouring of the GLOBAL matrix, pmg_mcsor_set_noise_row_offset(first global row),
+   and set up.  `dist`: any transport (pmg_dist_create[_ipc]; its grid may be NULL).  The per-colour scatter plan
+   (MatCreateScatters, src/mc_sor.c:152-214, de-duplicated per ghost column and split by the colour in which a value
+   changes): send_ptr[ncolors+1] / send_pos = layout positions (pmg_mcsor_get_layout) of my rows of colour c that some other
+   rank reads; counts[c*nranks + r] = length of rank r's list of colour c (the same array on every rank);
+   recv_ptr[ncolors+1] / recv_src / recv_pos = for every ghost row that changes in colour c its index in the colour's
+   gathered list (rank blocks in rank order) and its layout position.  Host arrays, copied; mc and dist are borrowed. */
+pmg_status pmg_distmcsor_create(pmg_mcsor mc, pmg_dist dist, int32_t ncolors, const int64_t *send_ptr, const int32_t *send_pos, const int64_t *counts, const int64_t *recv_ptr, const int32_t *recv_src, const int32_t *recv_pos, pmg_distmcsor *out);
+/* the sample loop / MCSORApply on layout vectors (my rows filled; ghost entries of y are refreshed inside): for every
+   colour, sweep its rows on the device, then update the ghost values (src/mc_sor.c:317-340), all on `stream`, no host
+   work between colours.  Collective.  Bit-identical to the single-process chain for any number of ranks. */
+pmg_status pmg_distmcsor_sample_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+pmg_status pmg_distmcsor_apply_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int sweep_type, void *stream);
+pmg_status pmg_distmcsor_destroy(pmg_distmcsor *h);
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* Multigrid Monte Carlo on a DMDA hierarchy: replaces PCGAMGMC with -pc_gamgmc_mg_type mg                  */
 /* (src/pc_gamgmc.c) and the PCMG V-cycle it drives                                                        */
 /* ------------------------------------------------------------------------------------------------------ */

@@ -175,3 +175,31 @@ extern "C" int pmgk_xch_pull(const pmgk_xch_args *a, unsigned *err, void *stream
   hipLaunchKernelGGL(xch_pull_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, err);
   return launch_status();
 }
+
+// ---- ghost updates of the row-block distributed sampler (pmg_distmcsor.c; reference VecScatter of src/mc_sor.c:318-319) ----
+namespace {
+__global__ __launch_bounds__(256) void gather_idx_kernel(int64_t n, const int32_t *__restrict__ idx, const double *__restrict__ src, double *__restrict__ dst)
+{
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < n) dst[q] = src[idx[q]];
+}
+__global__ __launch_bounds__(256) void scatter_idx_kernel(int64_t n, const int32_t *__restrict__ src_idx, const int32_t *__restrict__ dst_idx, const double *__restrict__ src, double *__restrict__ dst)
+{
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < n) dst[dst_idx[q]] = src[src_idx[q]];
+}
+} // namespace
+
+extern "C" int pmgk_gather_idx(int64_t n, const int32_t *idx, const double *src, double *dst, void *stream)
+{
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gather_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, idx, src, dst);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+extern "C" int pmgk_scatter_idx(int64_t n, const int32_t *src_idx, const int32_t *dst_idx, const double *src, double *dst, void *stream)
+{
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scatter_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, src_idx, dst_idx, src, dst);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}

@@ -138,7 +138,7 @@ pmg_status pmg_dist_get_unique_id(const char *rccl_path, void *id128)
    used to exercise the RCCL calls on one GPU. */
 pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void *id128, const char *rccl_path, int loopback, pmg_dist *out)
 {
-  PMG_CHECK(out && g, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(out, PMG_ERR_ARG_NULL, "null argument"); /* g == NULL: a transport without a slab (pmg_dist_exchange / _allgather only) */
   *out = NULL;
   PMG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, PMG_ERR_ARG_OUTOFRANGE, "rank %d of %d", rank, nranks);
   PMG_CHECK(!loopback || nranks == 1, PMG_ERR_ARG_WRONG, "loopback needs a single rank");
@@ -151,8 +151,9 @@ pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void 
   d->lo       = loopback ? rank : (rank > 0 ? rank - 1 : -1);
   d->hi       = loopback ? rank : (rank < nranks - 1 ? rank + 1 : -1);
   pmgk_grid_layout L;
-  pmg_status       st = pmg_grid_get_kernel_layout(g, &L);
-  d->nz               = L.nz;
+  memset(&L, 0, sizeof L);
+  pmg_status st = g ? pmg_grid_get_kernel_layout(g, &L) : PMG_SUCCESS;
+  d->nz         = L.nz;
   if (!st && (nranks > 1 || loopback)) {
     PMG_CHECK(id128, PMG_ERR_ARG_NULL, "null RCCL unique id");
     st = rccl_load(rccl_path, &d->api);
@@ -182,7 +183,7 @@ pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void 
 
 pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dist *out)
 {
-  PMG_CHECK(out && g, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(out, PMG_ERR_ARG_NULL, "null argument"); /* g == NULL: a transport without a slab */
   *out = NULL;
   PMG_CHECK(nranks >= 1 && nranks <= PMG_IPC_MAXRANKS && rank >= 0 && rank < nranks, PMG_ERR_ARG_OUTOFRANGE, "rank %d of %d", rank, nranks);
   pmg_dist d = (pmg_dist)calloc(1, sizeof *d);
@@ -194,9 +195,10 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
   d->lo        = rank > 0 ? rank - 1 : -1;
   d->hi        = rank < nranks - 1 ? rank + 1 : -1;
   pmgk_grid_layout L;
-  pmg_status       st = pmg_grid_get_kernel_layout(g, &L);
-  d->nz               = L.nz;
-  d->plane            = L.sp;
+  memset(&L, 0, sizeof L);
+  pmg_status st = g ? pmg_grid_get_kernel_layout(g, &L) : PMG_SUCCESS;
+  d->nz         = L.nz;
+  d->plane      = L.sp;
   d->gcap             = 2 * d->plane > ((int64_t)1 << 19) ? 2 * d->plane : ((int64_t)1 << 19); /* two colour planes of the fine level, or 4 MB */
   const size_t bytes  = sizeof(double) * (size_t)(PMG_IPC_HDR + 4 * d->plane + 6 * d->gcap); /* flags, colour planes, 4 generic slots, 2 gather areas */
   /* fine-grained device memory: flag words and planes are written by a PEER device while this device's kernels poll
@@ -627,6 +629,7 @@ static pmg_status dist_exchange(pmg_dist d, int c, double *y, hipEvent_t after)
 static pmg_status dist_sweeps(pmg_dist d, const double *b, double *y, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
 {
   PMG_CHECK(d && b && y, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(d->g, PMG_ERR_ARG_WRONGSTATE, "this transport was created without a grid slab");
   PMG_CHECK(its >= 0, PMG_ERR_ARG_OUTOFRANGE, "its = %d", its);
   PMG_CHECK(pmg_sweep_type_ok(sweep_type), PMG_ERR_SUP, "Only forward, backward and symmetric sweep supported");
   hipStream_t   s  = (hipStream_t)stream;

@@ -1,0 +1,169 @@
+/* MCSOR on a general AIJ matrix distributed by ROW BLOCKS, one rank per device -- host side (C11).
+ *
+ * Replaces MCSORApply_MPIAIJ (reference src/mc_sor.c:298-381): for every colour the ghost values are updated, then the
+ * colour's rows are swept.  The reference builds one VecScatter per colour (MatCreateScatters, :152-214) whose ghost
+ * buffer holds one entry per off-process NONZERO in row-visit order (:197-198, :332); here a rank's off-process COLUMNS
+ * are ghost rows of its local sliced-ELL operator (identity rows of an extra, never swept colour), every value travels
+ * once, and the whole loop -- colour sweeps and ghost updates -- runs in C on the caller's stream:
+ *
+ *   update of colour c:  gather  my rows of colour c that any other rank reads     (one kernel, index list)
+ *                        all-gather over the halo transport of pmg_dist.c          (ipc: one push into every rank's
+ *                                                                                    gather area + flag words; rccl: one
+ *                                                                                    group of ncclSend / ncclRecv)
+ *                        scatter what I read from the others into my ghost rows     (one kernel, index lists)
+ *
+ * The blocks of a colour tile one buffer in rank order, so the all-gather is the single-step form.  Every rank receives
+ * every boundary value of the colour, not only its own ghosts: with the rank counts of one node (<= 8) and boundary
+ * sets of a few thousand rows that is cheaper than a sparse all-to-all and reuses the transport as it stands.
+ * Noise is keyed on the global row (pmg_mcsor_set_noise_row_offset) and the entries of a row keep the order of the
+ * global CSR row, so the chain is the single-process chain bit for bit.
+ */
+#include "pmg_internal.h"
+
+struct pmg_distmcsor_s {
+  pmg_mcsor mc;   /* borrowed: local rows + ghost rows, set up */
+  pmg_dist  dist; /* borrowed: transport (any pmg_dist object; its grid is not used) */
+  int32_t   ncolors, nranks, rank;
+  /* per colour c: my send list [send_ptr[c], send_ptr[c+1]) of layout positions; the gather buffer of the colour holds
+     the ranks' blocks in rank order (offsets / counts [c*nranks + r]); my read list [recv_ptr[c], recv_ptr[c+1]) of
+     (index in the colour's gather buffer, layout position of the ghost row) */
+  int64_t *send_ptr, *recv_ptr, *goff, *gcnt, *gtot;
+  int32_t *send_pos_dev, *recv_src_dev, *recv_pos_dev;
+  double  *gbuf;
+  int64_t  gcap;
+};
+
+pmg_status pmg_distmcsor_destroy(pmg_distmcsor *hp)
+{
+  if (!hp || !*hp) return PMG_SUCCESS;
+  pmg_distmcsor h = *hp;
+  free(h->send_ptr);
+  free(h->recv_ptr);
+  free(h->goff);
+  free(h->gcnt);
+  free(h->gtot);
+  pmg_dev_free(h->send_pos_dev);
+  pmg_dev_free(h->recv_src_dev);
+  pmg_dev_free(h->recv_pos_dev);
+  pmg_dev_free(h->gbuf);
+  free(h);
+  *hp = NULL;
+  return PMG_SUCCESS;
+}
+
+/* mc: the local operator (my rows with the ghost columns appended as identity rows of colour `ncolors`), set up.
+   send_ptr[ncolors+1] / send_pos: layout positions of my rows of colour c that another rank reads, in the order of the
+   colour's block; counts[c*nranks + r]: length of rank r's block of colour c (identical on every rank);
+   recv_ptr[ncolors+1] / recv_src / recv_pos: for every ghost row that changes in colour c, its index in the colour's
+   gather buffer (blocks in rank order) and its layout position.  All arrays are host arrays and are copied. */
+pmg_status pmg_distmcsor_create(pmg_mcsor mc, pmg_dist dist, int32_t ncolors, const int64_t *send_ptr, const int32_t *send_pos, const int64_t *counts, const int64_t *recv_ptr, const int32_t *recv_src, const int32_t *recv_pos, pmg_distmcsor *out)
+{
+  PMG_CHECK(out, PMG_ERR_ARG_NULL, "null output handle");
+  *out = NULL;
+  PMG_CHECK(mc && dist && send_ptr && counts && recv_ptr, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(ncolors >= 1, PMG_ERR_ARG_OUTOFRANGE, "ncolors = %d", ncolors);
+  int32_t mcols = 0, ld = 0;
+  PMG_CALL(pmg_mcsor_get_num_colors(mc, &mcols));
+  PMG_CALL(pmg_mcsor_layout_len(mc, &ld));
+  PMG_CHECK(mcols == ncolors || mcols == ncolors + 1, PMG_ERR_ARG_SIZ, "the local operator has %d colours; expected %d swept colours (+ 1 for ghost rows)", mcols, ncolors);
+  pmg_distmcsor h = (pmg_distmcsor)calloc(1, sizeof *h);
+  PMG_CHECK(h, PMG_ERR_MEM, "out of host memory");
+  h->mc      = mc;
+  h->dist    = dist;
+  h->ncolors = ncolors;
+  pmg_status st = pmg_dist_get_info(dist, &h->rank, &h->nranks, &h->gcap);
+  const size_t nc1 = (size_t)ncolors + 1, ncr = (size_t)ncolors * (size_t)(h->nranks > 0 ? h->nranks : 1);
+  if (!st) {
+    h->send_ptr = (int64_t *)malloc(sizeof(int64_t) * nc1);
+    h->recv_ptr = (int64_t *)malloc(sizeof(int64_t) * nc1);
+    h->goff     = (int64_t *)malloc(sizeof(int64_t) * ncr);
+    h->gcnt     = (int64_t *)malloc(sizeof(int64_t) * ncr);
+    h->gtot     = (int64_t *)malloc(sizeof(int64_t) * nc1);
+    if (!h->send_ptr || !h->recv_ptr || !h->goff || !h->gcnt || !h->gtot) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+  }
+  int64_t maxtot = 0;
+  if (!st) {
+    memcpy(h->send_ptr, send_ptr, sizeof(int64_t) * nc1);
+    memcpy(h->recv_ptr, recv_ptr, sizeof(int64_t) * nc1);
+    memcpy(h->gcnt, counts, sizeof(int64_t) * ncr);
+    for (int32_t c = 0; c < ncolors && !st; ++c) {
+      int64_t off = 0;
+      for (int32_t r = 0; r < h->nranks; ++r) {
+        if (counts[(size_t)c * h->nranks + r] < 0) st = pmg_set_error(PMG_ERR_ARG_OUTOFRANGE, __FILE__, __LINE__, "negative block length");
+        h->goff[(size_t)c * h->nranks + r] = off;
+        off += counts[(size_t)c * h->nranks + r];
+      }
+      h->gtot[c] = off;
+      if (off > maxtot) maxtot = off;
+      if (!st && send_ptr[c + 1] - send_ptr[c] != counts[(size_t)c * h->nranks + h->rank]) st = pmg_set_error(PMG_ERR_ARG_SIZ, __FILE__, __LINE__, "colour %d: my send list has %lld entries but my block %lld", c, (long long)(send_ptr[c + 1] - send_ptr[c]), (long long)counts[(size_t)c * h->nranks + h->rank]);
+      if (!st && (send_ptr[c + 1] < send_ptr[c] || recv_ptr[c + 1] < recv_ptr[c])) st = pmg_set_error(PMG_ERR_ARG_WRONG, __FILE__, __LINE__, "list pointers must be monotone");
+    }
+    if (!st && (send_ptr[0] != 0 || recv_ptr[0] != 0)) st = pmg_set_error(PMG_ERR_ARG_WRONG, __FILE__, __LINE__, "list pointers must start at 0");
+  }
+  if (!st && maxtot > h->gcap) st = pmg_set_error(PMG_ERR_ARG_SIZ, __FILE__, __LINE__, "%lld boundary values of one colour exceed the exchange capacity of the transport (%lld)", (long long)maxtot, (long long)h->gcap);
+  const int64_t ns = st ? 0 : send_ptr[ncolors], nr = st ? 0 : recv_ptr[ncolors];
+  if (!st && ((ns > 0 && !send_pos) || (nr > 0 && (!recv_src || !recv_pos)))) st = pmg_set_error(PMG_ERR_ARG_NULL, __FILE__, __LINE__, "null index list");
+  for (int64_t q = 0; q < ns && !st; ++q)
+    if (send_pos[q] < 0 || send_pos[q] >= ld) st = pmg_set_error(PMG_ERR_ARG_OUTOFRANGE, __FILE__, __LINE__, "send position %d outside the layout (%d)", send_pos[q], ld);
+  for (int32_t c = 0; c < ncolors && !st; ++c)
+    for (int64_t q = recv_ptr[c]; q < recv_ptr[c + 1] && !st; ++q)
+      if (recv_pos[q] < 0 || recv_pos[q] >= ld || recv_src[q] < 0 || recv_src[q] >= h->gtot[c]) st = pmg_set_error(PMG_ERR_ARG_OUTOFRANGE, __FILE__, __LINE__, "colour %d: read entry %lld (source %d of %lld, position %d of %d) out of range", c, (long long)q, recv_src[q], (long long)h->gtot[c], recv_pos[q], ld);
+  if (!st) st = pmg_dev_upload((void **)&h->send_pos_dev, send_pos, sizeof(int32_t) * (size_t)ns);
+  if (!st) st = pmg_dev_upload((void **)&h->recv_src_dev, recv_src, sizeof(int32_t) * (size_t)nr);
+  if (!st) st = pmg_dev_upload((void **)&h->recv_pos_dev, recv_pos, sizeof(int32_t) * (size_t)nr);
+  if (!st) st = pmg_dev_alloc((void **)&h->gbuf, sizeof(double) * (size_t)(maxtot > 0 ? maxtot : 1));
+  if (st) {
+    pmg_distmcsor_destroy(&h);
+    return st;
+  }
+  *out = h;
+  return PMG_SUCCESS;
+}
+
+/* ghost update for the rows of colour c: VecScatterBegin/End of src/mc_sor.c:318-319 */
+static pmg_status distmcsor_update(pmg_distmcsor h, int32_t c, double *y, void *stream)
+{
+  if (h->gtot[c] == 0 || h->nranks == 1) return PMG_SUCCESS; /* identical on every rank */
+  const int64_t *off = h->goff + (size_t)c * h->nranks, *cnt = h->gcnt + (size_t)c * h->nranks;
+  const int64_t  ns = h->send_ptr[c + 1] - h->send_ptr[c], nr = h->recv_ptr[c + 1] - h->recv_ptr[c];
+  if (ns > 0) PMG_KERNEL(pmgk_gather_idx(ns, h->send_pos_dev + h->send_ptr[c], y, h->gbuf + off[h->rank], stream));
+  PMG_CALL(pmg_dist_allgather(h->dist, h->gbuf, off, cnt, stream));
+  if (nr > 0) PMG_KERNEL(pmgk_scatter_idx(nr, h->recv_src_dev + h->recv_ptr[c], h->recv_pos_dev + h->recv_ptr[c], h->gbuf, y, stream));
+  return PMG_SUCCESS;
+}
+
+static pmg_status distmcsor_sweeps(pmg_distmcsor h, const double *b, double *y, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+{
+  PMG_CHECK(h && b && y, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(its >= 0, PMG_ERR_ARG_OUTOFRANGE, "its = %d", its);
+  PMG_CHECK(pmg_sweep_type_ok(sweep_type), PMG_ERR_SUP, "Only forward, backward and symmetric sweep supported");
+  for (int32_t c = 0; c < h->ncolors; ++c) PMG_CALL(distmcsor_update(h, c, y, stream)); /* the caller's y has no ghost values yet */
+  uint64_t ctr = counter0;
+  for (int32_t it = 0; it < its; ++it) {
+    const int ndir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
+    for (int q = 0; q < ndir; ++q) {
+      const int dir = ndir == 2 ? (q == 0 ? PMG_SOR_FORWARD_SWEEP : PMG_SOR_BACKWARD_SWEEP) : sweep_type;
+      for (int32_t cc = 0; cc < h->ncolors; ++cc) {
+        const int32_t c = dir == PMG_SOR_FORWARD_SWEEP ? cc : h->ncolors - 1 - cc; /* src/mc_sor.c:317, :344 */
+        PMG_CALL(pmg_mcsor_sweep_color_layout(h->mc, c, noisy, scaled, seed, ctr, b, y, stream));
+        PMG_CALL(distmcsor_update(h, c, y, stream));
+      }
+      ++ctr; /* a symmetric sweep draws twice per sample, src/pc_mcgibbs.c:172-181 */
+    }
+  }
+  if (counter_out) *counter_out = ctr;
+  return PMG_SUCCESS;
+}
+
+/* `its` samples of the mcgibbs / sorgibbs chain on layout vectors (b, y: my rows filled; the ghost entries of y are
+   refreshed here).  Collective: every rank makes the same call. */
+pmg_status pmg_distmcsor_sample_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+{
+  return distmcsor_sweeps(h, b_lay, y_lay, its, 1, scaled, sweep_type, seed, counter0, counter_out, stream);
+}
+
+/* MCSORApply: one deterministic sweep of the given type */
+pmg_status pmg_distmcsor_apply_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int sweep_type, void *stream)
+{
+  return distmcsor_sweeps(h, b_lay, y_lay, 1, 0, 0, sweep_type, 0, 0, NULL, stream);
+}

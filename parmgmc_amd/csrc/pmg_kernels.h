@@ -162,6 +162,9 @@ int pmgk_xch_push(const pmgk_xch_args *a, unsigned *counter, void *stream);
 int pmgk_allgather_push(int nranks, int me, const double *src, int64_t n, double *const *dst_dev, int64_t dst_off, uint64_t *const *flag_dev, uint64_t value, unsigned *counter, void *stream);
 int pmgk_allgather_wait(int nranks, int me, const uint64_t *myflags, uint64_t value, unsigned *err, void *stream);
 int pmgk_xch_pull(const pmgk_xch_args *a, unsigned *err, void *stream);
+/* dst[q] = src[idx[q]];  dst[dst_idx[q]] = src[src_idx[q]]  (ghost updates of the row-block distributed sampler) */
+int pmgk_gather_idx(int64_t n, const int32_t *idx, const double *src, double *dst, void *stream);
+int pmgk_scatter_idx(int64_t n, const int32_t *src_idx, const int32_t *dst_idx, const double *src, double *dst, void *stream);
 int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream);
 
 #ifdef __cplusplus

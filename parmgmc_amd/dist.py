@@ -146,7 +146,7 @@ class RcclSlabDriver:
             if payload[0] is None:
                 raise RuntimeError(err or "rank 0 could not create the RCCL unique id")
             uid = C.create_string_buffer(payload[0], 128)
-        check(lib.pmg_dist_create(grid._h, rank, world, uid, pbytes, int(loopback), C.byref(self._h)))
+        check(lib.pmg_dist_create(grid._h if grid is not None else None, rank, world, uid, pbytes, int(loopback), C.byref(self._h)))  # grid None: a transport without a slab
         self._grid = grid  # keep alive
 
     def sample_cvec(self, b, y, its, scaled, sweep_type, seed, counter0):
@@ -191,7 +191,7 @@ class IpcSlabDriver(RcclSlabDriver):
         self._h = C.c_void_p()
         self._grid = grid
         if loopback:
-            check(lib.pmg_dist_create_ipc(grid._h, 0, 1, C.byref(self._h)))
+            check(lib.pmg_dist_create_ipc(grid._h if grid is not None else None, 0, 1, C.byref(self._h)))
             check(lib.pmg_dist_ipc_connect_loopback(self._h))
             return
         import torch.distributed as dist
@@ -200,7 +200,7 @@ class IpcSlabDriver(RcclSlabDriver):
         # agreement, so that no rank is left waiting in a collective the failing rank never enters
         err, blob, nb = None, None, C.c_int32()
         try:  # local phase: allocate the receive block, export its handle
-            check(lib.pmg_dist_create_ipc(grid._h, rank, world, C.byref(self._h)))
+            check(lib.pmg_dist_create_ipc(grid._h if grid is not None else None, rank, world, C.byref(self._h)))
             check(lib.pmg_dist_ipc_blob_bytes(C.byref(nb)))
             blob = C.create_string_buffer(nb.value)
             check(lib.pmg_dist_ipc_export(self._h, blob))
@@ -371,7 +371,9 @@ class DistMCSOR:
     torch.distributed point-to-point messages between them.  Noise is keyed on the global row, entries keep the order
     of the global CSR row: the chain is the single-process chain bit for bit."""
 
-    def __init__(self, rowptr, colidx, vals, row0, row1, n_global, colors, ncolors, rank, world, omega=1.0, sweep_type=SOR_FORWARD_SWEEP, scaled=True, group=None):
+    def __init__(self, rowptr, colidx, vals, row0, row1, n_global, colors, ncolors, rank, world, omega=1.0, sweep_type=SOR_FORWARD_SWEEP, scaled=True, group=None, transport=None):
+        import os
+
         import numpy as np
         import torch
         import torch.distributed as dist
@@ -430,6 +432,54 @@ class DistMCSOR:
             self.send.append(snd)
             self.recv.append(rcv)
         self._staged = dist.get_backend(group) != "nccl"  # gloo: through host memory
+        # --- the C driver (pmg_distmcsor.c): colour sweeps and ghost updates in one C loop on the stream, the updates as
+        # one all-gather of the colour's boundary values over the "ipc" or "rccl" transport of pmg_dist.c.  transport
+        # "torch" (or none available) keeps the Python loop over torch.distributed point-to-point messages below.
+        self._c, self._drv, self.transport = None, None, "none" if world == 1 else "torch"
+        want_tr = transport or os.environ.get("PMG_DIST_TRANSPORT")
+        if world > 1 and want_tr != "torch":
+            on_gpu = dist.get_backend(group) == "nccl"
+            for cand in ([want_tr] if want_tr else (["ipc", "rccl"] if on_gpu else [])):
+                ok, err, drv = 1, None, None
+                try:
+                    drv = IpcSlabDriver(None, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(None, rank, world, group=group)
+                except Exception as e:  # noqa: BLE001
+                    ok, err = 0, e
+                flag = torch.tensor([ok], device="cuda" if on_gpu else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if int(flag.item()) == 1:
+                    self._drv, self.transport = drv, cand
+                    break
+                if rank == 0:
+                    print(f"[parmgmc_amd] transport '{cand}' unavailable for the row-block sampler ({err if err else 'on another rank'})", flush=True)
+        if self._drv is not None:
+            import ctypes as C
+
+            from .capi import check, lib
+
+            others = [np.asarray(asked[p][rank], np.int64) for p in range(world) if p != rank]
+            needed = np.unique(np.concatenate(others)) if others else np.zeros(0, np.int64)  # my rows that another rank reads
+            send_lists = [needed[mycol[needed - row0] == c] for c in range(ncolors)]  # sorted global rows, by colour
+            all_lists = [None] * world
+            dist.all_gather_object(all_lists, send_lists, group=group)
+            counts = np.array([[len(all_lists[r][c]) for r in range(world)] for c in range(ncolors)], np.int64)
+            offs = np.concatenate([np.zeros((ncolors, 1), np.int64), np.cumsum(counts, axis=1)[:, :-1]], axis=1)
+            send_ptr = np.concatenate([[0], np.cumsum([len(l) for l in send_lists])]).astype(np.int64)
+            send_pos = (np.concatenate([pos[l - row0] for l in send_lists]) if send_ptr[-1] else np.zeros(0)).astype(np.int32)
+            gid = np.concatenate([want[p] for p in range(world)]) if ng else np.zeros(0, np.int64)  # my ghosts, by owner
+            gown = np.concatenate([np.full(len(want[p]), p) for p in range(world)]) if ng else np.zeros(0, np.int64)
+            gcol = np.concatenate([np.asarray(replies[p][rank] if p != rank else [], np.int64) for p in range(world)]) if ng else np.zeros(0, np.int64)
+            rsrc, rpos, rptr = [], [], [0]
+            for c in range(ncolors):
+                sel = np.nonzero(gcol == c)[0]
+                for q in sel:
+                    pown = int(gown[q])
+                    rsrc.append(int(offs[c, pown] + np.searchsorted(all_lists[pown][c], gid[q])))
+                    rpos.append(int(pos[self.nloc + np.searchsorted(self.ghosts, gid[q])]))
+                rptr.append(len(rsrc))
+            recv_ptr, recv_src, recv_pos = np.asarray(rptr, np.int64), np.asarray(rsrc, np.int32), np.asarray(rpos, np.int32)
+            self._c = C.c_void_p()
+            check(lib.pmg_distmcsor_create(self.mc._h, self._drv._h, ncolors, send_ptr.ctypes.data, send_pos.ctypes.data, np.ascontiguousarray(counts).ctypes.data, recv_ptr.ctypes.data, recv_src.ctypes.data, recv_pos.ctypes.data, C.byref(self._c)))
 
     def new_layout(self):
         import torch
@@ -466,6 +516,15 @@ class DistMCSOR:
 
     def sample_layout(self, b, y, its: int, seed: int, counter0: int = 0) -> int:
         """`its` samples on layout vectors (b: my rows filled, y: my rows filled; ghost entries are refreshed here)"""
+        if self._c is not None:  # the C loop: no Python between colours
+            import ctypes as C
+
+            from .capi import check, lib
+            from .wrappers import _ptr, _stream
+
+            out = C.c_uint64()
+            check(lib.pmg_distmcsor_sample_layout(self._c, _ptr(b), _ptr(y), its, int(self.scaled), self.sweep_type, seed, counter0, C.byref(out), _stream()))
+            return out.value
         for c in range(self.ncolors):
             self.exchange(y, c)
         ctr = counter0
@@ -477,3 +536,19 @@ class DistMCSOR:
                     self.exchange(y, c)
                 ctr += 1
         return ctr
+
+    def destroy(self):
+        if self._c is not None:
+            import ctypes as C
+
+            from .capi import lib
+
+            lib.pmg_distmcsor_destroy(C.byref(self._c))
+            self._c = None
+        self._drv = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

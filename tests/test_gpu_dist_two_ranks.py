@@ -213,7 +213,7 @@ def test_distributed_vcycle_reproduces_the_single_device_chain(grid, levels, wor
     assert np.array_equal(np.concatenate([x[1] for x in parts]), yd.cpu().numpy())
 
 
-def _csr_worker(rank, world, port, which, omega, sweep_type, its, q):
+def _csr_worker(rank, world, port, which, omega, sweep_type, its, q, transport=None):
     import torch
     import torch.distributed as dist
 
@@ -231,7 +231,8 @@ def _csr_worker(rank, world, port, which, omega, sweep_type, its, q):
     r0, r1 = cuts[rank], cuts[rank + 1]
     rp = A.rowptr[r0:r1 + 1] - A.rowptr[r0]
     sl = slice(A.rowptr[r0], A.rowptr[r1])
-    smp = DistMCSOR(rp, A.colidx[sl], A.vals[sl], r0, r1, n, colors[r0:r1], int(colors.max()) + 1, rank, world, omega=omega, sweep_type=sweep_type)
+    smp = DistMCSOR(rp, A.colidx[sl], A.vals[sl], r0, r1, n, colors[r0:r1], int(colors.max()) + 1, rank, world, omega=omega, sweep_type=sweep_type, transport=transport)
+    assert smp.transport == (transport or "torch") and (smp._c is not None) == (transport == "ipc")
     rng = np.random.default_rng(5)
     b_all, y_all = rng.standard_normal(n), rng.standard_normal(n)
     b = smp.to_layout(torch.as_tensor(b_all[r0:r1], device="cuda"))
@@ -260,10 +261,11 @@ def _csr_problem(which):
     return A, O.coloring_redblack(9, 7, 6)
 
 
-@pytest.mark.parametrize("which,world,sweep_type", [("lshape", 2, 1), ("lshape", 3, 3), ("grid", 4, 2)])
-def test_row_block_distributed_csr_sampler_reproduces_the_single_device_chain(which, world, sweep_type):
+@pytest.mark.parametrize("which,world,sweep_type,transport", [("lshape", 2, 1, None), ("lshape", 3, 3, None), ("grid", 4, 2, None), ("lshape", 2, 1, "ipc"), ("lshape", 3, 3, "ipc"), ("grid", 4, 2, "ipc")], ids=["lshape-2-torch", "lshape-3-sym-torch", "grid-4-bwd-torch", "lshape-2-c-ipc", "lshape-3-sym-c-ipc", "grid-4-bwd-c-ipc"])
+def test_row_block_distributed_csr_sampler_reproduces_the_single_device_chain(which, world, sweep_type, transport):
     """MCSORApply_MPIAIJ (reference src/mc_sor.c:298-381) on the device: the matrix split into contiguous row blocks,
-    ghost values exchanged before every colour (DistMCSOR over torch.distributed, gloo here), per-colour sliced-ELL
+    ghost values exchanged before every colour -- by the Python loop of DistMCSOR over torch.distributed (gloo here) or by
+    the C driver pmg_distmcsor.c over the "ipc" transport (no Python between colours) --, per-colour sliced-ELL
     sweeps with noise keyed on the global row -- against the single-device multicolour sampler with the same colouring,
     bit for bit (BASELINE config 4's matrix: the P1 operator of the reference's lshape.msh, refined once)."""
     import torch
@@ -275,7 +277,7 @@ def test_row_block_distributed_csr_sampler_reproduces_the_single_device_chain(wh
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_csr_worker, args=(r, world, port, which, omega, sweep_type, its, q)) for r in range(world)]
+    procs = [ctx.Process(target=_csr_worker, args=(r, world, port, which, omega, sweep_type, its, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     parts = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
