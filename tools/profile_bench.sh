@@ -7,8 +7,9 @@ export TMPDIR=/tmp
 out=gpurun_out/$tag
 rm -rf $out
 mkdir -p $out
-steps=200
-args="--steps $steps --warmup 100 --no-cpu-baseline $*"
+steps=${STEPS:-20}     # the driver runs bench.py --steps 20 --warmup 5: profile THAT command (STEPS / WARMUP override)
+warmup=${WARMUP:-5}
+args="--steps $steps --warmup $warmup --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $args --no-mgmc > $out/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_full -- python3 bench.py $args > $out/bench_trace_full.log 2>&1  # incl. the V-cycle lines
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $args --no-mgmc > $out/bench_fetch.log 2>&1

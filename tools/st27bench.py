@@ -48,3 +48,7 @@ big = torch.randn(3 * ld + 3 * 65536, dtype=torch.float64, device="cuda", genera
 for o1, o2 in ((0, 0), (512, 1024), (2048, 4096), (8192 + 16, 16384 + 48), (32768, 65536)):
     xb, bb, rb = big[0:ld], big[ld + o1: 2 * ld + o1], big[2 * ld + o2: 3 * ld + o2]
     print(f"residual, vectors at +0, ld+{o1}, 2ld+{o2} doubles: {timed(lambda: mg.level_residual(lv, bb, xb, rb), 50):8.1f} us")
+xz = torch.zeros_like(x)
+print(f"sweep noisy, x = 0 each time   {timed(lambda: (xz.zero_(), mg.level_sweep(lv, b, xz, noisy=True, seed=3, counter=1)), 100):8.1f} us (incl. zero fill + copy)")
+bs = b * 1e-3
+print(f"sweep noisy, small b            {timed(lambda: mg.level_sweep(lv, bs, x, noisy=True, seed=3, counter=1), 100):8.1f} us")
