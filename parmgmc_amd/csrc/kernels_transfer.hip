@@ -159,6 +159,131 @@ __global__ __launch_bounds__(256) void q1_prolong_add_full_kernel(pmgk_grid_layo
   *reinterpret_cast<d2t *>(px) = v;
 }
 
+// ---- paired forms of the two common-case kernels above (round 2) ---------------------------------------------------------
+// The per-point kernels are bound by the number of load INSTRUCTIONS (27 per coarse point, 16 per two fine points, many
+// of them lanes striding over every other element): `SQ_WAIT_INST_ANY` 72-75 % of the wave cycles.  Here a thread takes
+// TWO neighbouring points and fetches every line it needs as one 16-byte load; the value next to the pair comes from the
+// neighbouring lane (DPP full-wave shift) where that lane sits on the same line, from one extra load where it does not.
+// Same terms, same order as the kernels above, so the same bits.
+typedef double d2a __attribute__((ext_vector_type(2), aligned(8)));
+
+__device__ __forceinline__ double lane_prev(double v) // lane i <- lane i-1 (lane 0: 0)
+{
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_next(double v) // lane i <- lane i+1 (lane 63: 0)
+{
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false));
+}
+
+// restriction: thread = coarse points I = 2q, 2q+1 of line J.  A fine line (jj, kk) holds x = 2I in the colour array
+// c0 = (jj + kk) & 1 at m = I and x = 2I-1, 2I+1 in the other one at m = I-1, I: two 16-byte loads per fine line give
+// x = 2I, 2I+2 and x = 2I+1, 2I+3; x = 2I-1 is the previous thread's x = 2I+3.
+__global__ __launch_bounds__(256) void q1_restrict_pair_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int tplC, const double *__restrict__ r, double *__restrict__ bc)
+{
+  const int lane = threadIdx.x & 63;
+  const int flat = blockIdx.x * 256 + threadIdx.x, J = flat / tplC, q = flat - J * tplC, K = C.kz0 + blockIdx.z;
+  const bool live = J < C.ny; // lanes behind the last line keep running (DPP sources), on clamped addresses
+  const int  Jc = live ? J : C.ny - 1, I0 = 2 * q;
+  const bool has1 = I0 + 1 < C.nx;
+  const int32_t sx = (int32_t)L.sx, sp = (int32_t)L.sp, cs = (int32_t)L.cs;
+  const int     fj = 2 * Jc, fk = 2 * K;
+  const bool    own_left = lane == 0 || q == 0; // the lane before me is on another line (or there is none): load x = 2 I0 - 1 myself
+  double        s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int     kg   = fk + dz;
+    const bool    okz  = (unsigned)kg < (unsigned)L.nzg;
+    const int     kk   = okz ? kg : fk;
+    const int32_t zoff = (kk - L.kz0 + 1) * sp;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int     j    = fj + dy;
+      const bool    oky  = (unsigned)j < (unsigned)L.ny;
+      const int     jj   = oky ? j : fj;
+      const int32_t yoff = zoff + jj * sx;
+      const int     c0   = (jj + kk) & 1;                       // colour of the even fine points of this line
+      const double *ev   = r + (c0 ? cs : 0) + yoff + I0;       // x = 2 I0, 2 I0 + 2
+      const double *od   = r + (c0 ? 0 : cs) + yoff + I0;       // x = 2 I0 + 1, 2 I0 + 3
+      const d2a     E = *reinterpret_cast<const d2a *>(ev), O = *reinterpret_cast<const d2a *>(od); // pad slots are zero and inside the line
+      double        Lf = lane_prev(O.y);                        // x = 2 I0 - 1
+      if (own_left) Lf = I0 > 0 ? od[-1] : E.x;                // absent (x = -1): the centre, with weight 0 below
+      const double wyz = ((dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0));
+      const bool   ok  = oky && okz;
+      // the per-point kernel forms w0 = (wx * wy) * wz with wx first: (0.5 * wy) * wz and (1.0 * wy) * wz -- the same
+      // numbers as products of powers of two, so any association gives the same bits
+      const double wl0 = (ok && I0 > 0) ? 0.5 * wyz : 0.0, wm = ok ? wyz : 0.0;
+      const double wr0 = (ok && 2 * I0 + 1 < L.nx) ? 0.5 * wyz : 0.0;
+      s0 = s0 + wl0 * Lf;
+      s0 = s0 + wm * E.x;
+      s0 = s0 + wr0 * O.x;
+      const double wr1 = (ok && 2 * I0 + 3 < L.nx) ? 0.5 * wyz : 0.0;
+      s1 = s1 + (ok ? 0.5 * wyz : 0.0) * O.x; // x = 2 I1 - 1 = 2 I0 + 1 exists whenever I1 does
+      s1 = s1 + wm * E.y;
+      s1 = s1 + wr1 * O.y;
+    }
+  }
+  if (!live || I0 >= C.nx) return;
+  double *o = bc + I0 + (int64_t)C.nx * (Jc + (int64_t)C.ny * (K - C.kz0 + 1));
+  o[0]      = s0;
+  if (has1) o[1] = s1;
+}
+
+// prolongation: thread = the two same-colour fine points i0 = 4t + p, i1 = i0 + 2 (one 16-byte read-modify-write), whose
+// coarse neighbours in x are 2t, 2t+1, 2t+2: one 16-byte load per (cz, by) coarse line + the next lane's first value
+__global__ __launch_bounds__(256) void q1_prolong_add_pair_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int kbegin, int tplE, int csel, const double *__restrict__ ec, double *__restrict__ x)
+{
+  const int lane = threadIdx.x; // block (64, 4)
+  const int flat = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x, j = flat / tplE, t = flat - j * tplE;
+  const int k = kbegin + (int)(csel >= 0 ? blockIdx.z : blockIdx.z >> 1), c = csel >= 0 ? csel : (int)(blockIdx.z & 1); // k: local plane, -1 / nz = ghosts
+  const bool live = j < L.ny && 2 * t < L.sx;
+  const int  jc = j < L.ny ? j : L.ny - 1;
+  const int  kg = k + L.kz0, p = (c + jc + kg) & 1;
+  const int  i0 = 4 * t + p, i1 = i0 + 2;
+  const bool act0 = live && i0 < L.nx, act1 = act0 && i1 < L.nx;
+  const int32_t cnx = C.nx, cnxy = C.nx * C.ny;
+  const int     oddx = p, oddy = jc & 1, oddz = kg & 1;
+  const int     I0 = min(2 * t, cnx - 1); // clamped for the lanes behind the line end (their values feed nobody)
+  const int32_t base = ((kg >> 1) - C.kz0 + 1) * cnxy + (jc >> 1) * cnx;
+  const bool    own_right = lane == 63 || t == tplE - 1; // the next lane is on another line: fetch coarse 2t + 2 myself
+  double        s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int cz = 0; cz < 2; ++cz) {
+    const double wz = oddz ? 0.5 : (cz ? 0.0 : 1.0);
+#pragma unroll
+    for (int by = 0; by < 2; ++by) {
+      const double  wy  = oddy ? 0.5 : (by ? 0.0 : 1.0);
+      const double *row = ec + base + (cz & oddz) * cnxy + (by & oddy) * cnx;
+      double        A, B;
+      if (I0 + 1 < cnx) {
+        const d2a v = *reinterpret_cast<const d2a *>(row + I0);
+        A           = v.x;
+        B           = v.y;
+      } else {
+        A = B = row[I0];
+      }
+      double Cn = lane_next(A); // coarse 2t + 2 = the next thread's first value
+      if (own_right) Cn = (oddx && act1) ? row[I0 + 2] : B;
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax) {
+        const double wx = oddx ? 0.5 : (ax ? 0.0 : 1.0);
+        const double w  = wx * wy * wz;
+        // point 0 reads coarse 2t + (ax & oddx); point 1 the same shifted by one when it exists (else it is not stored)
+        const double v0 = (ax & oddx) ? B : A;
+        const double v1 = act1 ? ((ax & oddx) ? Cn : B) : v0;
+        s0              = s0 + w * v0;
+        s1              = s1 + w * v1;
+      }
+    }
+  }
+  if (!act0) return;
+  double *px = x + (int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)jc * L.sx + 2 * t;
+  d2t     v  = *reinterpret_cast<d2t *>(px);
+  v.x        = v.x + s0;
+  if (act1) v.y = v.y + s1;
+  *reinterpret_cast<d2t *>(px) = v;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 // all directions refined, natural coarse storage, and both vectors addressable with 32-bit byte offsets
@@ -179,7 +304,13 @@ extern "C" int pmgk_q1_restrict(const pmgk_grid_layout *L, const pmgk_st27_dims 
   const int  rx = C->nx != L->nx, ry = C->ny != L->ny, rz = C->nzg != L->nzg;
   const dim3 block(256), grid((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, C->nz);
   if (transfer_full_case(L, C, cpos)) {
-    hipLaunchKernelGGL(q1_restrict_full_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, r_cvec, bc);
+    static const int pair = getenv("PMG_TRANSFER_PAIR") ? atoi(getenv("PMG_TRANSFER_PAIR")) : 1;
+    if (pair) {
+      const int tplC = (C->nx + 1) / 2;
+      hipLaunchKernelGGL(q1_restrict_pair_kernel, dim3((unsigned)(((int64_t)C->ny * tplC + 255) / 256), 1, C->nz), block, 0, (hipStream_t)stream, *L, *C, tplC, r_cvec, bc);
+    } else {
+      hipLaunchKernelGGL(q1_restrict_full_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, r_cvec, bc);
+    }
     return launch_status();
   }
   hipLaunchKernelGGL(q1_restrict_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, cpos, r_cvec, bc);
@@ -194,7 +325,9 @@ extern "C" int pmgk_q1_prolong_add(const pmgk_grid_layout *L, const pmgk_st27_di
   const int  tplE = ((L->nx + 1) / 2 + 1) / 2;
   const dim3 block(64, 4), grid((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, only_color >= 0 ? kcount : 2 * kcount);
   if (transfer_full_case(L, C, cpos)) {
-    hipLaunchKernelGGL(q1_prolong_add_full_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, kbegin, tplE, only_color, ec, x_cvec);
+    static const int pair = getenv("PMG_TRANSFER_PAIR") ? atoi(getenv("PMG_TRANSFER_PAIR")) : 1;
+    if (pair) hipLaunchKernelGGL(q1_prolong_add_pair_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, kbegin, tplE, only_color, ec, x_cvec);
+    else hipLaunchKernelGGL(q1_prolong_add_full_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, kbegin, tplE, only_color, ec, x_cvec);
     return launch_status();
   }
   hipLaunchKernelGGL(q1_prolong_add_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, kbegin, tplE, only_color, cpos, ec, x_cvec);
