@@ -6,8 +6,8 @@
 // Set-up (O(N^3) flops, the one place of the sampler where the matrix cores pay): blocked right-looking
 // Cholesky with 32x32 tiles -- diagonal tile factored (and inverted) by one workgroup in LDS, panel = tile *
 // inverse-diagonal^T, trailing update C_ik -= L_ij L_kj^T on v_mfma_f64_16x16x4_f64 (one wavefront per 32x32
-// tile, 4 accumulators x 8 k-steps) -- followed by the blocked inverse W = L^-1, computed anti-diagonal by
-// anti-diagonal with the same MFMA tile product.
+// tile, 4 accumulators x 8 k-steps) -- followed by the blocked inverse W = L^-1, computed by recursive doubling over pairs of
+// inverted diagonal blocks with the same MFMA tile product.
 // Per sample: a triangular solve is a chain of N dependent steps, so the sample uses W: two triangular
 // matrix-vector products, one wavefront per row, reading W (stored twice: row-major lower and row-major upper
 // = W^T) exactly once -- HBM/L2 bound, 2 * N(N+1)/2 * 8 bytes.
@@ -120,26 +120,26 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(double *__restrict__ 
       }
 }
 
-// Inverse, anti-diagonal d >= 1: W_{j+d,j} = -Dinv_{j+d} * sum_{k=j}^{j+d-1} L_{j+d,k} W_{k,j}; one wavefront per j.
-// W holds Dinv on its diagonal tiles (d = 0, written by inv_diag_kernel).
-__global__ __launch_bounds__(64) void inv_step_kernel(const double *__restrict__ L, double *__restrict__ W, int64_t ld, int d, const double *__restrict__ Dinv)
+// Blocked inverse W = L^-1 by recursive doubling.  With the diagonal blocks A (tiles [a0, a0+m)) and B (tiles [a0+m, b1))
+// of a pair already inverted, the block below the diagonal is  W_BA = -W_BB (L_BA W_AA):  two tile products per level,
+//   phase 0:  T_{ib,ja} =  sum_{k in A, k >= ja} L_{ib,k} W_{k,ja}        (W_AA is lower triangular in tiles)
+//   phase 1:  W_{ib,ja} = -sum_{k in B, k <= ib} W_{ib,k} T_{k,ja}
+// one wavefront per 32x32 output tile on v_mfma_f64_16x16x4_f64, all pairs of a level in one launch: 2 log2(nt) launches
+// with thousands of independent tiles each, instead of nt - 1 anti-diagonal launches in which a handful of wavefronts
+// each ran a chain of up to nt tile products (round 1: 153 launches of ~300 us for 17^3 = 4913 rows, the largest entry of
+// the bench's kernel table although it is set-up).  grid = (m, m, pairs), tiles outside a ragged last block return.
+__global__ __launch_bounds__(64) void inv_pair_kernel(const double *__restrict__ L, double *__restrict__ W, double *__restrict__ T, int64_t ld, int m, int nt, int phase)
 {
-  __shared__ double T[NB][NB + 1];
-  const int j = blockIdx.x, i = j + d;
-  v4d       acc[2][2] = {};
-  mfma_tile32(acc, L + (int64_t)i * NB + (int64_t)j * NB * ld, ld, W + (int64_t)j * NB + (int64_t)j * NB * ld, ld, false, d * NB);
+  const int a0 = 2 * m * (int)blockIdx.z, b0 = a0 + m, b1 = min(b0 + m, nt);
+  const int ja = a0 + (int)blockIdx.x, ib = b0 + (int)blockIdx.y;
+  if (ib >= b1) return;
+  v4d acc[2][2] = {};
+  if (phase == 0) mfma_tile32(acc, L + (int64_t)ib * NB + (int64_t)ja * NB * ld, ld, W + (int64_t)ja * NB + (int64_t)ja * NB * ld, ld, false, (b0 - ja) * NB);
+  else mfma_tile32(acc, W + (int64_t)ib * NB + (int64_t)b0 * NB * ld, ld, T + (int64_t)b0 * NB + (int64_t)ja * NB * ld, ld, false, (ib - b0 + 1) * NB);
+  double *O = (phase == 0 ? T : W) + (int64_t)ib * NB + (int64_t)ja * NB * ld;
   for (int ti = 0; ti < 2; ++ti)
     for (int tj = 0; tj < 2; ++tj)
-      for (int reg = 0; reg < 4; ++reg) T[tile_row(ti, reg)][tile_col(tj)] = acc[ti][tj][reg];
-  __syncthreads();
-  const double *Di = Dinv + (int64_t)i * NB * NB; // lower triangular, column-major
-  double       *O  = W + (int64_t)i * NB + (int64_t)j * NB * ld;
-  for (int e = threadIdx.x; e < NB * NB; e += 64) {
-    const int r = e & (NB - 1), c = e >> 5;
-    double    s = 0.0;
-    for (int k = 0; k <= r; ++k) s = fma(Di[r + NB * k], T[k][c], s);
-    O[r + ld * c] = -s;
-  }
+      for (int reg = 0; reg < 4; ++reg) O[tile_row(ti, reg) + ld * tile_col(tj)] = phase == 0 ? acc[ti][tj][reg] : -acc[ti][tj][reg];
 }
 
 __global__ void inv_diag_kernel(double *__restrict__ W, int64_t ld, const double *__restrict__ Dinv)
@@ -203,8 +203,9 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 } // namespace
 
 // In-place lower Cholesky of the column-major npad x npad matrix A (npad a multiple of 32, padding = identity),
-// then W = L^-1 (column-major, same shape).  Dinv: npad/32 tiles of 32x32 scratch.  info: device int, 0 on entry.
-extern "C" int pmgk_potrf_inverse(int32_t npad, double *A, double *W, double *Dinv, int *info, void *stream)
+// then W = L^-1 (column-major, same shape; zero on entry).  T: scratch of the same shape, Dinv: npad/32 tiles of 32x32
+// scratch.  info: device int, 0 on entry.
+extern "C" int pmgk_potrf_inverse(int32_t npad, double *A, double *W, double *T, double *Dinv, int *info, void *stream)
 {
   hipStream_t s  = (hipStream_t)stream;
   const int   nt = npad / NB;
@@ -218,7 +219,10 @@ extern "C" int pmgk_potrf_inverse(int32_t npad, double *A, double *W, double *Di
     }
   }
   hipLaunchKernelGGL(inv_diag_kernel, dim3(nt), dim3(256), 0, s, W, (int64_t)npad, Dinv);
-  for (int d = 1; d < nt; ++d) hipLaunchKernelGGL(inv_step_kernel, dim3(nt - d), dim3(64), 0, s, A, W, (int64_t)npad, d, Dinv);
+  for (int m = 1; m < nt; m *= 2) { // blocks of m tiles are inverted: pair them
+    const int pairs = (nt + 2 * m - 1) / (2 * m);
+    for (int phase = 0; phase < 2; ++phase) hipLaunchKernelGGL(inv_pair_kernel, dim3(m, m, pairs), dim3(64), 0, s, A, W, T, (int64_t)npad, m, nt, phase);
+  }
   return launch_status();
 }
 

@@ -68,22 +68,24 @@ pmg_status pmg_chol_create_csr_lowrank(int32_t n, const int32_t *rowptr, const i
   }
   ch->n    = n;
   ch->npad = npad;
-  double    *W = NULL, *Dinv = NULL;
+  double    *W = NULL, *T = NULL, *Dinv = NULL;
   int       *info_dev = NULL, info = 0;
   pmg_status st = pmg_dev_upload((void **)&ch->L_dev, A, nn * sizeof(double));
   free(A);
   if (!st) st = pmg_dev_alloc((void **)&W, nn * sizeof(double));
+  if (!st) st = pmg_dev_alloc((void **)&T, nn * sizeof(double)); /* scratch of the blocked inverse */
   if (!st) st = pmg_dev_alloc((void **)&Dinv, sizeof(double) * 32 * 32 * (size_t)(npad / 32));
   if (!st) st = pmg_dev_alloc((void **)&info_dev, sizeof(int));
   if (!st) st = pmg_dev_alloc((void **)&ch->W_lo, sizeof(double) * (size_t)n * n);
   if (!st) st = pmg_dev_alloc((void **)&ch->W_up, sizeof(double) * (size_t)n * n);
   if (!st) st = pmg_dev_alloc((void **)&ch->v, sizeof(double) * (size_t)n);
   if (!st) st = pmg_dev_alloc((void **)&ch->xi, sizeof(double) * (size_t)n);
-  if (!st && pmgk_potrf_inverse(npad, ch->L_dev, W, Dinv, info_dev, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "Cholesky kernels failed to launch"); /* LAPACKpotrf_("L"), :188 */
+  if (!st && pmgk_potrf_inverse(npad, ch->L_dev, W, T, Dinv, info_dev, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "Cholesky kernels failed to launch"); /* LAPACKpotrf_("L"), :188 */
   if (!st && pmgk_pack_rowmajor(n, W, npad, 0, ch->W_lo, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "pack kernel failed to launch");
   if (!st && pmgk_pack_rowmajor(n, W, npad, 1, ch->W_up, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "pack kernel failed to launch");
   if (!st && hipMemcpy(&info, info_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device Cholesky failed");
   pmg_dev_free(W);
+  pmg_dev_free(T);
   pmg_dev_free(Dinv);
   pmg_dev_free(info_dev);
   if (!st && info) st = pmg_set_error(PMG_ERR_MAT_CH_ZRPVT, __FILE__, __LINE__, "Dense Cholesky failed: leading minor of order %d is not positive definite", info); /* :190 */

@@ -94,7 +94,7 @@ int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, c
    given explicitly (transfer operators between level layouts); accumulate != 0 adds to y */
 int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, void *stream);
 /* dense lower Cholesky in place + W = L^-1 on the device (npad multiple of 32; MFMA f64 trailing updates) */
-int pmgk_potrf_inverse(int32_t npad, double *A_colmajor, double *W_colmajor, double *Dinv_scratch, int *info_dev, void *stream);
+int pmgk_potrf_inverse(int32_t npad, double *A_colmajor, double *W_colmajor, double *T_scratch, double *Dinv_scratch, int *info_dev, void *stream);
 int pmgk_pack_rowmajor(int32_t n, const double *in_colmajor, int64_t ld, int transpose, double *out_rowmajor, void *stream);
 /* class-stencil form of a 27-point (9-point) Galerkin operator on an nx*ny*nzg grid: coef[27*cls + e], cls = position
    class (first / interior / last per direction), e = 9(dz+1) + 3(dy+1) + (dx+1); idiag = (1/d)*omega, sqrtdiag per
