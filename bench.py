@@ -499,6 +499,7 @@ def main() -> None:
             break
         if rank == 0:
             print(f"[bench] halo transport {tr!r} rejected: {res['err'] or res.get('halo_check') or 'failed on another rank'}", file=sys.stderr, flush=True)
+        res["smp"].destroy()  # collective, orderly: the next transport allocates and exports fresh blocks
         res = None
         torch.cuda.empty_cache()
     if res is None:
@@ -548,6 +549,7 @@ def main() -> None:
             print(json.dumps(out), flush=True)
 
     if not args.no_mgmc and os.environ.get("PMG_BENCH_NO_MGMC") != "1":
+        smp.destroy()  # collective: unmap peers, barrier, free -- the secondary lines build their own transports
         del b, y, smp, g, res
         torch.cuda.empty_cache()
         dog.arm(float(os.environ.get("PMG_BENCH_SECONDARY_TIMEOUT", "300")), "secondary lines")  # a hang here: headline printed with "hang": true, exit code 3

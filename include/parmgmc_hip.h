@@ -232,6 +232,9 @@ pmg_status pmg_dist_allgather(pmg_dist d, double *buf_dev, const int64_t *offset
 pmg_status pmg_dist_check(pmg_dist d);
 /* rank / number of ranks / largest message (doubles) the generic exchange can carry */
 pmg_status pmg_dist_get_info(pmg_dist d, int32_t *rank, int32_t *nranks, int64_t *capacity);
+/* ipc transport: unmap the peers' receive blocks.  Orderly tear-down when further transports follow: every rank
+   disconnects, the caller runs a barrier, every rank destroys (frees its own block). */
+pmg_status pmg_dist_ipc_disconnect(pmg_dist d);
 pmg_status pmg_dist_destroy(pmg_dist *d);
 
 /* ------------------------------------------------------------------------------------------------------ */

@@ -129,6 +129,7 @@ _sig = {
     "pmg_dist_ipc_connect_loopback": (_int, [_vp]),
     "pmg_dist_sample_cvec": (_int, [_vp, _vp, _vp, _i32, _int, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_dist_destroy": (_int, [C.POINTER(_vp)]),
+    "pmg_dist_ipc_disconnect": (_int, [_vp]),
     "pmg_distmcsor_create": (_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "pmg_distmcsor_sample_layout": (_int, [_vp, _vp, _vp, _i32, _int, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_distmcsor_apply_layout": (_int, [_vp, _vp, _vp, _int, _vp]),

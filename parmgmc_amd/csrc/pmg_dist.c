@@ -411,6 +411,28 @@ static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its
   return PMG_SUCCESS;
 }
 
+/* Unmap the peers' receive blocks.  Tear-down of the ipc transport is a three-step protocol when more objects are to be
+   created afterwards: every rank disconnects, the caller runs a barrier, then every rank destroys (which frees its own
+   block).  Freeing a block that a peer still has mapped and exporting a fresh one right away made hipIpcGetMemHandle fail
+   with "invalid argument" on this runtime (seen with 4 ranks; pmg_dist_destroy alone still unmaps, without the barrier). */
+pmg_status pmg_dist_ipc_disconnect(pmg_dist d)
+{
+  PMG_CHECK(d, PMG_ERR_ARG_NULL, "null dist object");
+  if (d->transport != 1) return PMG_SUCCESS;
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < d->nranks && d->all_connected; ++r) {
+    if (d->all_block[r] && r != d->lo && r != d->hi && r != d->rank) (void)hipIpcCloseMemHandle(d->all_block[r]);
+    d->all_block[r] = NULL;
+  }
+  d->all_connected = 0;
+  for (int side = 0; side < 2 && !d->loopback; ++side) {
+    if (d->peer_block[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
+    d->peer_block[side] = NULL;
+    d->peer_recv[side] = d->peer_grecv[side] = NULL;
+  }
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_dist_destroy(pmg_dist *dp)
 {
   if (!dp || !*dp) return PMG_SUCCESS;

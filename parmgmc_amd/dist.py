@@ -127,6 +127,7 @@ class RcclSlabDriver:
         from .capi import check, lib
 
         self._h = C.c_void_p()
+        self._world, self._group = world, group
         path = capi.torch_rccl_path()
         pbytes = path.encode() if path else None
         uid = None
@@ -165,6 +166,24 @@ class RcclSlabDriver:
 
         check(lib.pmg_dist_check(self._h))
 
+    def destroy(self):
+        """Collective, orderly tear-down: unmap the peers' blocks, barrier, free the own block (a rank that frees a block
+        a peer still has mapped and exports a fresh one at once gets "invalid argument" from hipIpcGetMemHandle)."""
+        import ctypes as C
+
+        from .capi import lib
+
+        if not self._h:
+            return
+        lib.pmg_dist_ipc_disconnect(self._h)
+        if getattr(self, "_world", 1) > 1:
+            import torch
+            import torch.distributed as dist
+
+            torch.cuda.synchronize()
+            dist.barrier(group=getattr(self, "_group", None))
+        lib.pmg_dist_destroy(C.byref(self._h))
+
     def __del__(self):
         try:
             import ctypes as C
@@ -190,6 +209,7 @@ class IpcSlabDriver(RcclSlabDriver):
 
         self._h = C.c_void_p()
         self._grid = grid
+        self._world, self._group = (1 if loopback else world), group
         if loopback:
             check(lib.pmg_dist_create_ipc(grid._h if grid is not None else None, 0, 1, C.byref(self._h)))
             check(lib.pmg_dist_ipc_connect_loopback(self._h))
@@ -308,6 +328,12 @@ class DistGridSampler:
         if self.rccl is not None:
             self.rccl.check()
 
+    def destroy(self):
+        """collective: orderly tear-down of the halo transport (call on every rank before building another one)"""
+        if self.rccl is not None:
+            self.rccl.destroy()
+            self.rccl = None
+
     def sample_cvec(self, b, y, its: int, seed: int, counter0: int = 0) -> int:
         if self.world == 1:
             self.grid.set_sweep_type(self.sweep_type)
@@ -356,6 +382,8 @@ class DistMGMC:
 
     def destroy(self):
         self.mg.destroy()  # before the transport and the grid it borrows
+        if self.grid_sampler is not None:
+            self.grid_sampler.destroy()
         self.grid_sampler = None
 
 
@@ -545,6 +573,8 @@ class DistMCSOR:
 
             lib.pmg_distmcsor_destroy(C.byref(self._c))
             self._c = None
+        if self._drv is not None:
+            self._drv.destroy()
         self._drv = None
 
     def __del__(self):
