@@ -29,7 +29,8 @@ def balls(n, k, seed=0):
 
 
 n, levels = int(sys.argv[1]) if len(sys.argv) > 1 else 257, 5
-for k in (0, 3, 17):
+import os
+for k in ([int(os.environ["K"])] if "K" in os.environ else (0, 3, 17)):
     mg = MGMC(n, n, n, 10.0, levels)
     if k:
         B, S = balls(n, k)
