@@ -102,8 +102,8 @@ struct pair_ctx {
 // line (row 4) needs the first colour's new values on both sides -- own register and the neighbouring lane's, one
 // wave shuffle -- and the rows behind it (5..8) are kept (12 values) until then.  Keeping all 36 values of the
 // neighbourhood instead costs 130 VGPRs and two fifths of the occupancy.
-template <bool NOISY, bool FIRST1, class RowFn>
-__device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, const double *s_coef, const double *s_idiag, const double *s_sqrtd, const pmg::LogTabEntry *s_logtab, d2 bb)
+template <bool NOISY, bool FIRST1, class RowFn, class ZeroFn>
+__device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, ZeroFn &&row_is_zero, const double *s_coef, const double *s_idiag, const double *s_sqrtd, const pmg::LogTabEntry *s_logtab, d2 bb)
 {
   constexpr int F = FIRST1 ? 1 : 0, S = 1 - F;
   const int     cyz   = 3 * pos_class(C.j, C.ny) + 9 * pos_class(C.k, C.nzg);
@@ -132,6 +132,13 @@ __device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, con
   double        oldF = 0.0, oldS = 0.0, keep[4][3];
 #pragma unroll
   for (int row = 0; row < 9; ++row) {
+    // a row known to hold zeros (first sweep from a zero guess): its terms are skipped altogether -- they would subtract
+    // +-0 -- and nothing is loaded; after unrolling the test is a compile-time constant
+    if (row_is_zero(row)) {
+      if (row > 4)
+        for (int q = 0; q < 3; ++q) keep[row - 5][q] = 0.0;
+      continue;
+    }
     double r[4];
     get_row(row, r);
 #pragma unroll
@@ -158,9 +165,11 @@ __device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, con
   accS            = accS - cfS[12] * (FIRST1 ? nb : nF);
   accS            = accS - cfS[14] * (FIRST1 ? nF : nb);
 #pragma unroll
-  for (int row = 5; row < 9; ++row)
+  for (int row = 5; row < 9; ++row) {
+    if (row_is_zero(row)) continue;
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) accS = accS - cfS[3 * row + dx + 1] * keep[row - 5][dx + 1];
+  }
   double nS = C.om1 * oldS + s_idiag[clsS] * accS;
   nS        = (S ? C.act1 : C.act0) ? nS : 0.0;
   const d2 out = {F ? nS : nF, F ? nF : nS};
@@ -184,7 +193,9 @@ __device__ __forceinline__ void load_row(double (&r)[4], const double *vec, int 
 #ifndef PMG_ST27_PAIR_WAVES
 #define PMG_ST27_PAIR_WAVES 5
 #endif
-template <bool NOISY, bool BACKWARD>
+// ZIN: y_in is all zeros and is not read (the pre-smoothing sweep of a V-cycle level starts from a zero guess: no memset of
+// the level's iterate, no loads of zeros); ZOTHER: the planes of the other z-parity are zero too (first phase of such a sweep)
+template <bool NOISY, bool BACKWARD, bool ZIN, bool ZOTHER>
 __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(PMG_ST27_PAIR_WAVES, 8))) void st27_pair_phase_kernel(pmgk_st27 S, int nbx, int nby, int nbz, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, const double *y_in, double *y_out, const double *y_other)
 {
   __shared__ double           s_coef[27 * 27], s_idiag[27], s_sqrtd[27];
@@ -238,9 +249,11 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
       auto          rows = [&](int row, double (&r)[4]) {
         const int dz = row / 3 - 1, dy = row % 3 - 1;
         const bool okz = dz < 0 ? hasD : (dz > 0 ? hasU : true);
-        load_row(r, (dz != 0 && okz) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jA), okz ? C.k + dz : C.k);
+        load_row(r, (dz != 0 && (okz || ZIN)) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jA), okz ? C.k + dz : C.k); // ZIN: y_in does not exist; an absent plane is replaced by y_other's centre plane (finite, zero coefficients)
       };
-      nw = sweep_pair<NOISY, BACKWARD>(C, rows, s_coef, s_idiag, s_sqrtd, s_logtab, bb);
+      // stage A reads only old values: in-plane rows from y_in, the planes above / below from y_other
+      auto zero = [&](int row) { return (row / 3 == 1) ? ZIN : ZOTHER; };
+      nw = sweep_pair<NOISY, BACKWARD>(C, rows, zero, s_coef, s_idiag, s_sqrtd, s_logtab, bb);
       const bool owned   = BACKWARD ? w >= 1 : w < PT; // the other first-stage line belongs to the neighbouring tile
       if (owned && final_lane && C.act0) {
         if (C.act1) *reinterpret_cast<d2u *>(y_out + lrow) = d2u{nw.x, nw.y};
@@ -272,9 +285,11 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
           return;
         }
         const bool okz = dz < 0 ? hasD : (dz > 0 ? hasU : true);
-        load_row(r, (dz != 0 && okz) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jB), okz ? C.k + dz : C.k);
+        load_row(r, (dz != 0 && (okz || ZIN)) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jB), okz ? C.k + dz : C.k);
       };
-      const d2 nw = sweep_pair<NOISY, BACKWARD>(C, rows, s_coef, s_idiag, s_sqrtd, s_logtab, bb);
+      // stage B: the own line is old (y_in), the lines above / below in this plane are stage A's new values (LDS)
+      auto zero = [&](int row) { return (row / 3 == 1) ? (row == 4 && ZIN) : ZOTHER; };
+      const d2 nw = sweep_pair<NOISY, BACKWARD>(C, rows, zero, s_coef, s_idiag, s_sqrtd, s_logtab, bb);
       if (final_lane && C.act0) {
         if (C.act1) *reinterpret_cast<d2u *>(y_out + lrow) = d2u{nw.x, nw.y};
         else y_out[lrow] = nw.x;
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(256) void st27_pair_residual_kernel(pmgk_st27 S, in
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
-template <bool NOISY, bool BACKWARD>
+template <bool NOISY, bool BACKWARD, bool ZIN = false, bool ZOTHER = false>
 void launch_phase(const pmgk_st27 &S, int pz, double om1, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, const double *y_other, hipStream_t s)
 {
   const int cz = (S.nzg - pz + 1) / 2; // planes of this parity
@@ -339,7 +354,7 @@ void launch_phase(const pmgk_st27 &S, int pz, double om1, uint64_t seed, uint64_
   const int  npairs = (S.nx + 1) / 2;
   const int  nbx = (npairs + VALID - 1) / VALID, nby = (S.ny + 2 * PT - 1) / (2 * PT);
   const dim3 grid(xcd_grid(nbx, nby, cz)), block(64, PT + 1);
-  hipLaunchKernelGGL((st27_pair_phase_kernel<NOISY, BACKWARD>), grid, block, 0, s, S, nbx, nby, cz, pz, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y_in, y_out, y_other);
+  hipLaunchKernelGGL((st27_pair_phase_kernel<NOISY, BACKWARD, ZIN, ZOTHER>), grid, block, 0, s, S, nbx, nby, cz, pz, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y_in, y_out, y_other);
 }
 
 } // namespace
@@ -348,19 +363,29 @@ void launch_phase(const pmgk_st27 &S, int pz, double om1, uint64_t seed, uint64_
 // Single-device levels only (all planes owned: kz0 = 0, nz = nzg).
 extern "C" int pmgk_st27_sweep_pp(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, void *stream)
 {
+  // y_in == NULL: the sweep starts from a ZERO vector, which is neither stored nor read (omega-independent: the old value
+  // enters as (1 - omega) * 0)
   if (S->kz0 != 0 || S->nz != S->nzg || y_in == y_out) return 1;
   const double om1 = 1. - omega;
   hipStream_t  s   = (hipStream_t)stream;
+  const bool   zin = y_in == nullptr;
   for (int phase = 0; phase < 2; ++phase) {
     const int     pz    = backward ? 1 - phase : phase;
     const double *other = phase == 0 ? y_in : y_out;
+#define PMG_PHASE(N, B) \
+  do { \
+    if (!zin) launch_phase<N, B, false, false>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s); \
+    else if (phase == 0) launch_phase<N, B, true, true>(*S, pz, om1, seed, sweep, b, y_out, y_out, y_out, s); /* pointers unused: any valid address */ \
+    else launch_phase<N, B, true, false>(*S, pz, om1, seed, sweep, b, y_out, y_out, other, s); \
+  } while (0)
     if (noisy) {
-      if (backward) launch_phase<true, true>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s);
-      else launch_phase<true, false>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s);
+      if (backward) PMG_PHASE(true, true);
+      else PMG_PHASE(true, false);
     } else {
-      if (backward) launch_phase<false, true>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s);
-      else launch_phase<false, false>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s);
+      if (backward) PMG_PHASE(false, true);
+      else PMG_PHASE(false, false);
     }
+#undef PMG_PHASE
   }
   return launch_status();
 }

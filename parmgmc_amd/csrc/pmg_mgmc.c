@@ -42,6 +42,7 @@ typedef struct {
   pmg_mcsor mc;
   int64_t   ld;
   double   *b, *x, *r;
+  int       x_unset; /* the iterate is zero but the memset was skipped: the next out-of-place sweep starts from NULL */
   double   *x2; /* second buffer of the out-of-place class-stencil sweep (single-device levels): x and x2 swap after every directional sweep */
   /* transfers to the next coarser level, in layout numbering on the device */
   int32_t  P_nrows, R_nrows;
@@ -510,10 +511,12 @@ static int st27_use_pair(const mg_level *Lv)
 
 /* one directional sweep of a class-stencil level on (b, *x): in place, or out of place into Lv->x2 followed by a swap of
    the two buffers when x is the level's own iterate */
-static pmg_status st27_one_sweep(mg_level *Lv, const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, void *stream)
+static pmg_status st27_one_sweep(mg_level *Lv, const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, int x_is_zero, void *stream)
 {
   if (Lv->x2 && st27_use_pair(Lv)) {
-    PMG_KERNEL(pmgk_st27_sweep_pp(S, backward, omega, noisy, seed, sweep, b, Lv->x, Lv->x2, stream));
+    /* x_is_zero: the iterate is the zero vector and has NOT been stored (level_iterate_is_unset): the sweep neither reads it
+       nor needs the memset */
+    PMG_KERNEL(pmgk_st27_sweep_pp(S, backward, omega, noisy, seed, sweep, b, x_is_zero ? NULL : Lv->x, Lv->x2, stream));
     double *t = Lv->x;
     Lv->x     = Lv->x2;
     Lv->x2    = t;
@@ -1255,7 +1258,8 @@ static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, 
         PMG_KERNEL(pmgk_st27_sweep_phase(&S, backward, 1, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
         PMG_CALL(halo_level(h, Lv, Lv->x, stream));
       } else {
-        PMG_CALL(st27_one_sweep(Lv, &S, backward, h->omega, 1, seed, (*ctr)++, rhs, stream));
+        PMG_CALL(st27_one_sweep(Lv, &S, backward, h->omega, 1, seed, (*ctr)++, rhs, Lv->x_unset, stream));
+        Lv->x_unset = 0;
       }
       if (Lv->lrc) PMG_CALL(pmg_lrc_rhs_done(Lv->lrc, stream));
       if (Lv->lrc) PMG_CALL(pmg_lrc_post(Lv->lrc, backward ? PMG_SOR_BACKWARD_SWEEP : PMG_SOR_FORWARD_SWEEP, Lv->x, stream)); /* src/mc_sor.c:101-112 */
@@ -1360,7 +1364,11 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
   for (int l = 0; l <= top; ++l) ctr[l] = sample * MG_DRAWS_PER_SAMPLE;
   for (int l = top; l >= 1; --l) {
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
-    if (l < top || !top_has_guess) PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
+    if (l < top || !top_has_guess) {
+      /* class-stencil levels with the out-of-place sweep: no memset, the first sweep is told that its input is zero */
+      if (Lv->x2 && st27_use_pair(Lv) && !Lv->lrc && h->nu >= 1) Lv->x_unset = 1;
+      else PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
+    }
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
     else if (Lv->is_st27) {
