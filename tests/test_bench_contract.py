@@ -46,3 +46,27 @@ def test_watchdog_reports_a_hang_with_a_nonzero_exit_code():
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert r.returncode == 3 and line["hang"] is True and line["value"] is None and line["n_gpus"] == 4
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields():
+    """one small end-to-end run of bench.py on the GPU: ONE JSON line with the driver's fields, `roofline` and `cpu_baseline`"""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--grid-n", "64", "--steps", "4", "--warmup", "2", "--no-mgmc", "--cpu-n", "32"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1) < 1e-9 and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["algorithmic_bytes_per_launch"] == 12 * 64 ** 3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "samples/s"
+    assert d["finite"] is True and d["clock_settle"]["settle_launches"] > 0
