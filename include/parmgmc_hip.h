@@ -352,6 +352,9 @@ pmg_status pmg_mgmc_get_level_stencil(pmg_mgmc mg, int32_t level, double *coef_2
 pmg_status pmg_mgmc_level_sweep(pmg_mgmc mg, int32_t level, int backward, int noisy, uint64_t seed, uint64_t counter, const double *b_lvl, double *x_lvl, void *stream);
 pmg_status pmg_mgmc_level_residual(pmg_mgmc mg, int32_t level, const double *b_lvl, const double *x_lvl, double *r_lvl, void *stream);
 pmg_status pmg_mgmc_level_restrict(pmg_mgmc mg, int32_t level, double *r_fine_lvl, double *b_coarse_lvl, void *stream);
+/* b_coarse = P^T (b - A x) as the V-cycle forms it on a single-device grid level (one kernel, same bits as
+   level_residual + level_restrict); PMG_ERR_SUP on levels where the cycle runs the two steps */
+pmg_status pmg_mgmc_level_residual_restrict(pmg_mgmc mg, int32_t level, const double *b_lvl, const double *x_lvl, double *b_coarse_lvl, void *stream);
 pmg_status pmg_mgmc_level_prolong_add(pmg_mgmc mg, int32_t level, const double *e_coarse_lvl, double *x_fine_lvl, void *stream);
 pmg_status pmg_mgmc_destroy(pmg_mgmc *mg);
 

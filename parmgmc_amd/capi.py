@@ -167,6 +167,7 @@ _sig = {
     "pmg_mgmc_level_sweep": (_int, [_vp, _i32, _int, _int, _u64, _u64, _vp, _vp, _vp]),
     "pmg_mgmc_level_residual": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "pmg_mgmc_level_restrict": (_int, [_vp, _i32, _vp, _vp, _vp]),
+    "pmg_mgmc_level_residual_restrict": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "pmg_mgmc_level_prolong_add": (_int, [_vp, _i32, _vp, _vp, _vp]),
     "pmg_initialize": (_int, []),
     "pmg_finalize": (_int, []),

@@ -331,16 +331,18 @@ __device__ __forceinline__ d2 residual_pair(const residual_consts &K, bool hasW0
   return out;
 }
 
+// the residuals of the four points 4t .. 4t+3 of line (j, k): outA = points 4t, 4t+2 (colour (j + k) & 1, the even x),
+// outB = points 4t+1, 4t+3 (zeros behind the line end)
 template <bool PACKED>
-__device__ __forceinline__ void grid_residual_body(const pmgk_grid_layout &L, const pmgk_grid_op &op, int t, int j, int k, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+__device__ __forceinline__ void grid_residual_values(const pmgk_grid_layout &L, const pmgk_grid_op &op, int t, int j, int k, const double *__restrict__ b, const double *__restrict__ y, int64_t &offa, int64_t &offb, d2 &outA, d2 &outB)
 {
-  if (j >= L.ny || 2 * t >= L.sx || 4 * t >= L.nx) return;
   const int      kg   = k + L.kz0;
   const int      ca   = (j + kg) & 1; // colour of the points 4t, 4t+2 (p = 0); the other colour owns 4t+1, 4t+3 (p = 1)
   const bool     hasS = j > 0, hasN = j < L.ny - 1, hasD = kg > 0, hasU = kg < L.nzg - 1;
   const int64_t  rowoff = (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx; // scalar row bases + 32-bit lane byte offsets, as in the sweep
   const uint32_t lo     = 16u * (uint32_t)t;
-  const int64_t  offa = (int64_t)ca * L.cs + rowoff, offb = (int64_t)(1 - ca) * L.cs + rowoff;
+  offa = (int64_t)ca * L.cs + rowoff;
+  offb = (int64_t)(1 - ca) * L.cs + rowoff;
   const double  *ya = y + offa, *yb = y + offb;
   const int64_t  dS = hasS ? L.sx : 0, dN = hasN ? L.sx : 0, dD = hasD ? L.sp : 0, dU = hasU ? L.sp : 0;
   const d2       Ya = ld2(at_bytes(ya, lo)), Yb = ld2(at_bytes(yb, lo));
@@ -356,13 +358,187 @@ __device__ __forceinline__ void grid_residual_body(const pmgk_grid_layout &L, co
   K.aD = hasD ? K.a : 0.0;
   K.aU = hasU ? K.a : 0.0;
   const int i0 = 4 * t;
-  { // colour ca: points i0, i0+2, neighbours in the other colour's array
-    const d2 out = residual_pair(K, i0 > 0, i0 < L.nx - 1, i0 + 2 < L.nx - 1, i0 + 2 < L.nx, ld2(at_bytes(yb - dD, lo)), ld2(at_bytes(yb - dS, lo)), ld2(at_bytes(yb + dN, lo)), ld2(at_bytes(yb + dU, lo)), edA, Yb.x, Yb.x, Yb.y, Ya, ld2(at_bytes(b + offa, lo)));
-    *reinterpret_cast<d2 *>(at_bytes(r + offa, lo)) = out;
+  // colour ca: points i0, i0+2, neighbours in the other colour's array
+  outA = residual_pair(K, i0 > 0, i0 < L.nx - 1, i0 + 2 < L.nx - 1, i0 + 2 < L.nx, ld2(at_bytes(yb - dD, lo)), ld2(at_bytes(yb - dS, lo)), ld2(at_bytes(yb + dN, lo)), ld2(at_bytes(yb + dU, lo)), edA, Yb.x, Yb.x, Yb.y, Ya, ld2(at_bytes(b + offa, lo)));
+  outB = d2{0.0, 0.0};
+  if (i0 + 1 < L.nx) // the other colour: points i0+1, i0+3
+    outB = residual_pair(K, true, i0 + 1 < L.nx - 1, i0 + 3 < L.nx - 1, i0 + 3 < L.nx, ld2(at_bytes(ya - dD, lo)), ld2(at_bytes(ya - dS, lo)), ld2(at_bytes(ya + dN, lo)), ld2(at_bytes(ya + dU, lo)), Ya.x, Ya.y, Ya.y, edB, Yb, ld2(at_bytes(b + offb, lo)));
+}
+
+template <bool PACKED>
+__device__ __forceinline__ void grid_residual_body(const pmgk_grid_layout &L, const pmgk_grid_op &op, int t, int j, int k, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+{
+  if (j >= L.ny || 2 * t >= L.sx || 4 * t >= L.nx) return;
+  int64_t offa, offb;
+  d2      outA, outB;
+  grid_residual_values<PACKED>(L, op, t, j, k, b, y, offa, offb, outA, outB);
+  const uint32_t lo = 16u * (uint32_t)t;
+  *reinterpret_cast<d2 *>(at_bytes(r + offa, lo)) = outA;
+  if (4 * t + 1 < L.nx) *reinterpret_cast<d2 *>(at_bytes(r + offb, lo)) = outB;
+}
+
+// ---- residual + Q1 restriction in one pass (single-device grid level of the V-cycle) --------------------------------
+// b_coarse = P^T (b - A y) without writing r: saves one write and one read of a fine vector per cycle.  Thread = the
+// coarse points I = 2t, 2t+1 of ONE coarse line J, i.e. the fine points 4t-1 .. 4t+3 of the fine lines 2J-1, 2J, 2J+1,
+// marching through the fine planes of a chunk of coarse planes.  Values by x parity: ev = y at x = 4t, 4t+2, od = y at
+// x = 4t+1, 4t+3; x = 4t-1 and 4t+4 are the neighbouring lanes' values (DPP), so lanes 0 and 63 of a wavefront only
+// supply their neighbours (62 of 64 store).  The residuals are formed by the expression of the residual kernel and
+// summed in the order of q1_restrict_pair_kernel (planes, then lines, then x), so the result has the SAME BITS as
+// residual-then-restrict.  The threads of a coarse plane are numbered line after line and dealt to the wavefronts without
+// gaps; XCD x takes a contiguous run of the (chunk, wavefront) list.
+// The z neighbours stay in registers: the thread carries its three fine lines of the planes k-1 and k through the march
+// and loads plane k+1 once (it is U now, C in the next step, D in the one after); only the lines beside its three (S of
+// the first, N of the last) are fetched per plane: 16 loads per plane step, and every y plane crosses the L2 once per
+// thread instead of three times -- between two uses lie the steps of all resident wavefronts, 10+ MB per XCD, beyond
+// its L2.  Measured (tools/rrbench.py): 513^3 578 us against 1064 us for the two kernels, 257^3 88 against 152 us; the
+// variant that re-loads the z neighbours per plane (rolling window over lines instead) took 833 / 122 us.
+__device__ __forceinline__ double lane_prev_d(double v) // lane i <- lane i-1
+{
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_next_d(double v) // lane i <- lane i+1
+{
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false));
+}
+
+struct rr_acc {
+  double s0, s1;
+};
+struct rr_thread {
+  int      t, J0;
+  uint32_t lo;
+  bool     left, right0, right1;                 // the fine points 4t-1, 4t+1, 4t+3 exist
+  bool     eW0, eE0, eE1, eV1;                   // even points 4t, 4t+2: neighbours / existence as residual_pair wants them
+  bool     oE0, oE1, oV1, ovalid;                // odd points 4t+1, 4t+3
+};
+
+__device__ __forceinline__ void rr_add(rr_acc &a, double wyz, const rr_thread &T, double Lf, const d2 &E, const d2 &O)
+{
+  const double h = 0.5 * wyz;
+  a.s0 = a.s0 + (T.left ? h : 0.0) * Lf;
+  a.s0 = a.s0 + wyz * E.x;
+  a.s0 = a.s0 + (T.right0 ? h : 0.0) * O.x;
+  a.s1 = a.s1 + h * O.x;
+  a.s1 = a.s1 + wyz * E.y;
+  a.s1 = a.s1 + (T.right1 ? h : 0.0) * O.y;
+}
+
+struct rr_line {
+  d2 ev, od;
+};
+
+__device__ __forceinline__ rr_line rr_load_line(const double *__restrict__ v, uint32_t base, uint32_t cs8, int parity)
+{
+  const uint32_t c = parity ? cs8 : 0u;
+  rr_line        r;
+  r.ev = ld2(at_bytes(v, base + c));
+  r.od = ld2(at_bytes(v, base + (cs8 - c)));
+  return r;
+}
+
+__global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_layout L, pmgk_grid_op op, pmgk_st27_dims C, int tplE, int wpp, int kc, int nchunks, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ bc)
+{
+  const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3, per = (int)gridDim.x >> 3;
+  const int gw  = __builtin_amdgcn_readfirstlane((xcd * per + q) * 4 + (int)(threadIdx.x >> 6));
+  const int zc = gw / wpp, wv = gw - zc * wpp;
+  if (zc >= nchunks) return; // whole wavefront
+  const int  lane = threadIdx.x & 63, nslots = C.ny * tplE;
+  const int  fu = 62 * wv + lane - 1, f = min(max(fu, 0), nslots - 1);
+  const bool store = lane >= 1 && lane <= 62 && fu < nslots;
+  rr_thread  T;
+  const int  Jc = f / tplE;
+  T.t      = f - Jc * tplE;
+  T.J0     = Jc;
+  T.lo     = 16u * (uint32_t)T.t;
+  const int i0 = 4 * T.t, I0 = 2 * T.t;
+  T.left   = I0 > 0;
+  T.right0 = i0 + 1 < L.nx;
+  T.right1 = i0 + 3 < L.nx;
+  T.eW0    = i0 > 0;
+  T.eE0    = i0 < L.nx - 1;
+  T.eE1    = i0 + 2 < L.nx - 1;
+  T.eV1    = i0 + 2 < L.nx;
+  T.oE0    = i0 + 1 < L.nx - 1;
+  T.oE1    = i0 + 3 < L.nx - 1;
+  T.oV1    = i0 + 3 < L.nx;
+  T.ovalid = i0 + 1 < L.nx;
+  const int      K0 = zc * kc, K1 = min(K0 + kc, C.nz);
+  const int      kfirst = max(2 * K0 - 1, 0), klast = min(2 * K1 - 1, L.nzg - 1), jmax = L.ny - 1;
+  const uint32_t sx8 = 8u * (uint32_t)L.sx, cs8 = 8u * (uint32_t)L.cs, sp8 = 8u * (uint32_t)L.sp;
+  const double   ma = -op.h2;
+  rr_acc         a = {0.0, 0.0}, n = {0.0, 0.0};
+  double        *out = bc + I0 + (int64_t)C.nx * (Jc + (int64_t)C.ny * (K0 + 1));
+  const int64_t  cplane = (int64_t)C.nx * C.ny;
+  rr_line        Dv[3], Cv[3], Uv[3];
+  {
+    const int kd = max(kfirst - 1, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int      jc = min(max(2 * Jc - 1 + i, 0), jmax);
+      const uint32_t ln = (uint32_t)jc * sx8 + T.lo;
+      Dv[i] = rr_load_line(y, (uint32_t)(kd + 1) * sp8 + ln, cs8, (jc + kd) & 1);
+      Cv[i] = rr_load_line(y, (uint32_t)(kfirst + 1) * sp8 + ln, cs8, (jc + kfirst) & 1);
+    }
   }
-  if (i0 + 1 < L.nx) { // the other colour: points i0+1, i0+3
-    const d2 out = residual_pair(K, true, i0 + 1 < L.nx - 1, i0 + 3 < L.nx - 1, i0 + 3 < L.nx, ld2(at_bytes(ya - dD, lo)), ld2(at_bytes(ya - dS, lo)), ld2(at_bytes(ya + dN, lo)), ld2(at_bytes(ya + dU, lo)), Ya.x, Ya.y, Ya.y, edB, Yb, ld2(at_bytes(b + offb, lo)));
-    *reinterpret_cast<d2 *>(at_bytes(r + offb, lo)) = out;
+  for (int k = kfirst; k <= klast; ++k) {
+    int J = Jc; // per plane: what depends on the lines alone would otherwise be kept in registers across the march
+    asm volatile("" : "+v"(J));
+    const bool     hasD = k > 0, hasU = k < L.nzg - 1, odd = k & 1; // wave-uniform
+    const int      nzc = (int)hasD + (int)hasU, ku = hasU ? k + 1 : k;
+    const double   dg2 = uniform(op.diag[nzc + 2]), dg3 = uniform(op.diag[nzc + 3]), dg4 = uniform(op.diag[nzc + 4]);
+    const double   wz = odd ? 0.5 : 1.0;
+    const uint32_t pl = (uint32_t)(k + 1) * sp8, plu = (uint32_t)(ku + 1) * sp8;
+    const int      jS = min(max(2 * J - 2, 0), jmax), jN = min(max(2 * J + 2, 0), jmax);
+    const rr_line  hS = rr_load_line(y, pl + (uint32_t)jS * sx8 + T.lo, cs8, (jS + k) & 1);
+    const rr_line  hN = rr_load_line(y, pl + (uint32_t)jN * sx8 + T.lo, cs8, (jN + k) & 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int      jc = min(max(2 * J - 1 + i, 0), jmax);
+      Uv[i] = rr_load_line(y, plu + (uint32_t)jc * sx8 + T.lo, cs8, (jc + ku) & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int      j = 2 * J - 1 + i, jc = min(max(j, 0), jmax);
+      const rr_line  bb = rr_load_line(b, pl + (uint32_t)jc * sx8 + T.lo, cs8, (jc + k) & 1);
+      const rr_line &S = i == 0 ? hS : Cv[i > 0 ? i - 1 : 0], &N = i == 2 ? hN : Cv[i < 2 ? i + 1 : 2];
+      const bool     hasS = jc > 0, hasN = jc < jmax, inner = hasS && hasN;
+      residual_consts Kc;
+      Kc.a  = ma;
+      Kc.dA = inner ? dg3 : dg2;
+      Kc.dB = inner ? dg4 : dg3;
+      Kc.aS = hasS ? ma : 0.0;
+      Kc.aN = hasN ? ma : 0.0;
+      Kc.aD = hasD ? ma : 0.0;
+      Kc.aU = hasU ? ma : 0.0;
+      const double edA = lane_prev_d(Cv[i].od.y), edB = lane_next_d(Cv[i].ev.x);
+      const d2     E = residual_pair(Kc, T.eW0, T.eE0, T.eE1, T.eV1, Dv[i].ev, S.ev, N.ev, Uv[i].ev, edA, Cv[i].od.x, Cv[i].od.x, Cv[i].od.y, Cv[i].ev, bb.ev);
+      d2           O = residual_pair(Kc, true, T.oE0, T.oE1, T.oV1, Dv[i].od, S.od, N.od, Uv[i].od, Cv[i].ev.x, Cv[i].ev.y, Cv[i].ev.y, edB, Cv[i].od, bb.od);
+      if (!T.ovalid) O = d2{0.0, 0.0};
+      const double Lf = lane_prev_d(O.y);
+      const double w  = ((unsigned)j < (unsigned)L.ny) ? (i == 1 ? wz : 0.5 * wz) : 0.0;
+      rr_add(a, w, T, Lf, E, O);
+      if (odd) rr_add(n, w, T, Lf, E, O);
+    }
+    if (odd) { // plane 2K+1 closes coarse plane K (unless it only opened the chunk's first one) and opens K+1
+      if (k > 2 * K0 - 1) {
+        if (store) {
+          out[0] = a.s0;
+          if (I0 + 1 < C.nx) out[1] = a.s1;
+        }
+        out += cplane;
+      }
+      a = n;
+      n = rr_acc{0.0, 0.0};
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Dv[i] = Cv[i];
+      Cv[i] = Uv[i];
+    }
+  }
+  if (2 * K1 - 1 > klast && store) { // the top coarse plane has no plane above it
+    out[0] = a.s0;
+    if (I0 + 1 < C.nx) out[1] = a.s1;
   }
 }
 
@@ -490,6 +666,27 @@ extern "C" int pmgk_grid_residual(const pmgk_grid_layout *L, const pmgk_grid_op 
   if (M.packed) hipLaunchKernelGGL((grid_residual_kernel<true, false>), M.grid, block, 0, (hipStream_t)stream, *L, *op, M.bandw, tplE, 0, 0, b, y, r);
   else if (M.tail) hipLaunchKernelGGL((grid_residual_kernel<false, true>), M.grid, block, 0, (hipStream_t)stream, *L, *op, M.bandw, tplE, M.tmain, M.tailw, b, y, r);
   else hipLaunchKernelGGL((grid_residual_kernel<false, false>), M.grid, block, 0, (hipStream_t)stream, *L, *op, M.bandw, tplE, 0, 0, b, y, r);
+  return launch_status();
+}
+
+// b_coarse = P^T (b - A y) in one launch; returns -1 (nothing launched) where the fused kernel does not apply: z-slabs,
+// semicoarsened or permuted coarse levels
+extern "C" int pmgk_grid_residual_restrict(const pmgk_grid_layout *L, const pmgk_grid_op *op, const pmgk_st27_dims *C, const double *b, const double *y, double *bc, void *stream)
+{
+  static const int off    = getenv("PMG_GRID_FUSED_RR") ? !atoi(getenv("PMG_GRID_FUSED_RR")) : 0;
+  static const int kc_env = getenv("PMG_GRID_RR_CHUNK") ? atoi(getenv("PMG_GRID_RR_CHUNK")) : 0;
+  const int        tplE   = grid_threads_per_line(L);
+  if (off || L->kz0 != 0 || L->nz != L->nzg || C->kz0 != 0 || C->nz != C->nzg) return -1;
+  if (L->nx < 3 || L->ny < 3 || L->nzg < 3 || !(L->nx & 1) || !(L->ny & 1) || !(L->nzg & 1)) return -1;
+  if (C->nx != (L->nx + 1) / 2 || C->ny != (L->ny + 1) / 2 || C->nzg != (L->nzg + 1) / 2) return -1;
+  if (tplE != (C->nx + 1) / 2 || (int64_t)C->ny * tplE >= ((int64_t)1 << 30)) return -1;
+  if (2 * (int64_t)L->cs * 8 >= ((int64_t)1 << 32)) return -1; // 32-bit byte offsets inside a vector
+  const int     wpp = (int)(((int64_t)C->ny * tplE + 61) / 62);
+  int           kc  = kc_env > 0 ? kc_env : 8; // coarse planes per chunk: each chunk re-reads one fine plane
+  while (kc_env <= 0 && kc > 2 && (int64_t)wpp * ((C->nz + kc - 1) / kc) < 2048) kc >>= 1;
+  const int     nchunks = (C->nz + kc - 1) / kc;
+  const int64_t nblocks = ((int64_t)wpp * nchunks + 3) / 4;
+  hipLaunchKernelGGL(grid_residual_restrict_kernel, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, *L, *op, *C, tplE, wpp, kc, nchunks, b, y, bc);
   return launch_status();
 }
 

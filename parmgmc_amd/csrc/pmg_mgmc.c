@@ -1370,6 +1370,12 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       else PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
     }
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
+    if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev) { /* b_{l-1} = P^T (b - A x) in one pass */
+      const pmgk_st27_dims CD = level_dims(Cc);
+      int                  done = 0;
+      PMG_CALL(pmg_grid_residual_restrict(Lv->g, Lv->b, Lv->x, &CD, Cc->b, &done, stream));
+      if (done) continue;
+    }
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
     else if (Lv->is_st27) {
       if (st27_use_pair(Lv)) PMG_KERNEL(pmgk_st27_residual_pair(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
@@ -1533,6 +1539,21 @@ pmg_status pmg_mgmc_level_restrict(pmg_mgmc h, int32_t level, double *r_fine, do
   PMG_CALL(level_checked(h, level, 1, &Lv));
   PMG_CHECK(r_fine && b_coarse, PMG_ERR_ARG_NULL, "null vector");
   return mg_restrict(h, level, r_fine, b_coarse, stream);
+}
+
+/* the V-cycle's fused step b_coarse = P^T (b - A x) on a grid level; PMG_ERR_SUP where the cycle runs the two steps */
+pmg_status pmg_mgmc_level_residual_restrict(pmg_mgmc h, int32_t level, const double *b_lvl, const double *x_lvl, double *b_coarse, void *stream)
+{
+  mg_level *Lv;
+  PMG_CALL(level_checked(h, level, 1, &Lv));
+  PMG_CHECK(b_lvl && x_lvl && b_coarse, PMG_ERR_ARG_NULL, "null vector");
+  int done = 0;
+  if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev) {
+    const pmgk_st27_dims CD = level_dims(&h->lv[level - 1]);
+    PMG_CALL(pmg_grid_residual_restrict(Lv->g, b_lvl, x_lvl, &CD, b_coarse, &done, stream));
+  }
+  PMG_CHECK(done, PMG_ERR_SUP, "level %d: no fused residual + restriction (z-slab, low-rank update, permuted or semicoarsened coarse level)", level);
+  return PMG_SUCCESS;
 }
 
 pmg_status pmg_mgmc_level_prolong_add(pmg_mgmc h, int32_t level, const double *e_coarse, double *x_fine, void *stream)

@@ -357,6 +357,9 @@ class MGMC:
     def level_restrict(self, level: int, r_fine, b_coarse):
         check(lib.pmg_mgmc_level_restrict(self._h, level, _ptr(r_fine), _ptr(b_coarse), _stream()))
 
+    def level_residual_restrict(self, level: int, b, x, b_coarse):
+        check(lib.pmg_mgmc_level_residual_restrict(self._h, level, _ptr(b), _ptr(x), _ptr(b_coarse), _stream()))
+
     def level_prolong_add(self, level: int, e_coarse, x_fine):
         check(lib.pmg_mgmc_level_prolong_add(self._h, level, _ptr(e_coarse), _ptr(x_fine), _stream()))
 

@@ -1,0 +1,67 @@
+"""The V-cycle's fused residual + restriction on the grid level (grid_residual_restrict_kernel) gives the SAME BITS as
+the residual kernel followed by the restriction kernel (both pinned to the oracle row by row in
+test_gpu_fullsize_oracle.py), on cubes, boxes and at BASELINE's hierarchy sizes; and the oracle's rows directly."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dims,levels", [((9, 9, 9), 2), ((17, 9, 33), 2), ((33, 33, 33), 3), ((65, 33, 17), 3), ((129, 129, 129), 4), ((257, 257, 257), 5), ((513, 513, 513), 6), ((253, 5, 9), 2)])
+def test_fused_equals_residual_then_restrict(dims, levels):
+    import torch
+
+    from parmgmc_amd import MGMC
+
+    nx, ny, nz = dims
+    mg = MGMC(nx, ny, nz, 7.0, levels).setup()
+    top = levels - 1
+    kind, ld, _ = mg.level_layout(top)
+    assert kind == 0
+    kc, ldc, offc = mg.level_layout(top - 1)
+    gen = torch.Generator(device="cuda").manual_seed(nx + ny)
+    # vectors in the level's own layout; the pad slots of a cvec hold zeros, as the hierarchy keeps them
+    from parmgmc_amd import GridMCSOR
+
+    g = GridMCSOR(nx, ny, nz, 7.0)
+    assert g.cvec_len == ld
+    b = g.to_cvec(torch.randn(nx * ny * nz, dtype=torch.float64, device="cuda", generator=gen))
+    x = g.to_cvec(torch.randn(nx * ny * nz, dtype=torch.float64, device="cuda", generator=gen))
+    r = torch.zeros(ld, dtype=torch.float64, device="cuda")
+    two = torch.zeros(ldc, dtype=torch.float64, device="cuda")
+    one = torch.full((ldc,), 3.0, dtype=torch.float64, device="cuda")  # every owned entry must be written
+    mg.level_residual(top, b, x, r)
+    mg.level_restrict(top, r, two)
+    mg.level_residual_restrict(top, b, x, one)
+    cn = ((nx + 1) // 2) * ((ny + 1) // 2) * ((nz + 1) // 2)
+    assert torch.equal(one[offc:offc + cn], two[offc:offc + cn])
+    assert float((one[:offc] - 3.0).abs().max()) == 0.0 and float((one[offc + cn:] - 3.0).abs().max()) == 0.0  # ghost planes untouched
+    if nx * ny * nz <= 129 ** 3:  # the oracle's restriction of the oracle's residual, all rows
+        rows = np.arange(nx * ny * nz, dtype=np.int64)
+        bh, xh = g.from_cvec(b).cpu().numpy(), g.from_cvec(x).cpu().numpy()
+        rh = O.grid7_rows_residual(nx, ny, nz, 7.0, rows, bh, xh)
+        crow = np.arange(cn, dtype=np.int64)
+        want = O.q1_rows_restrict((nx, ny, nz), ((nx + 1) // 2, (ny + 1) // 2, (nz + 1) // 2), crow, rh)
+        assert np.array_equal(one[offc:offc + cn].cpu().numpy(), want)
+    mg.destroy()
+
+
+def test_vcycle_uses_the_fused_kernel_and_keeps_its_samples():
+    """one sample of the 33^3 hierarchy equals the sample of the same hierarchy built level by level with the two-step
+    path (PMG_GRID_FUSED_RR=0 in a child process)"""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import torch, sys; sys.path.insert(0, %r); from parmgmc_amd import MGMC;"
+        "mg = MGMC(33, 33, 33, 5.0, 3).setup(); b = torch.ones(33**3, dtype=torch.float64, device='cuda');"
+        "y = torch.zeros_like(b); mg.sample(b, y, 3, seed=11); print(y.double().cpu().numpy().tobytes().hex())"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, PMG_GRID_FUSED_RR=flag)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, check=True).stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 33 ** 3 * 16
