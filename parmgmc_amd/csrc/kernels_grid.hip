@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
   rr_acc         a = {0.0, 0.0}, n = {0.0, 0.0};
   double        *out = bc + I0 + (int64_t)C.nx * (Jc + (int64_t)C.ny * (K0 + 1));
   const int64_t  cplane = (int64_t)C.nx * C.ny;
-  rr_line        Dv[3], Cv[3], Uv[3];
+  rr_line        Dv[3], Cv[3], Uv[3], hS, hN; // hS, hN: the lines 2J-2 and 2J+2 of the plane k (S of the first line, N of the last)
   {
     const int kd = max(kfirst - 1, 0);
 #pragma unroll
@@ -479,6 +479,9 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
       Dv[i] = rr_load_line(y, (uint32_t)(kd + 1) * sp8 + ln, cs8, (jc + kd) & 1);
       Cv[i] = rr_load_line(y, (uint32_t)(kfirst + 1) * sp8 + ln, cs8, (jc + kfirst) & 1);
     }
+    const int jS = min(max(2 * Jc - 2, 0), jmax), jN = min(max(2 * Jc + 2, 0), jmax);
+    hS = rr_load_line(y, (uint32_t)(kfirst + 1) * sp8 + (uint32_t)jS * sx8 + T.lo, cs8, (jS + kfirst) & 1);
+    hN = rr_load_line(y, (uint32_t)(kfirst + 1) * sp8 + (uint32_t)jN * sx8 + T.lo, cs8, (jN + kfirst) & 1);
   }
   for (int k = kfirst; k <= klast; ++k) {
     int J = Jc; // per plane: what depends on the lines alone would otherwise be kept in registers across the march
@@ -488,9 +491,11 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
     const double   dg2 = uniform(op.diag[nzc + 2]), dg3 = uniform(op.diag[nzc + 3]), dg4 = uniform(op.diag[nzc + 4]);
     const double   wz = odd ? 0.5 : 1.0;
     const uint32_t pl = (uint32_t)(k + 1) * sp8, plu = (uint32_t)(ku + 1) * sp8;
+    // the lines beside the thread's three are fetched a plane ahead like its own: in the step in which their owners load
+    // them, so that one of the two requests finds the line in the L2
     const int      jS = min(max(2 * J - 2, 0), jmax), jN = min(max(2 * J + 2, 0), jmax);
-    const rr_line  hS = rr_load_line(y, pl + (uint32_t)jS * sx8 + T.lo, cs8, (jS + k) & 1);
-    const rr_line  hN = rr_load_line(y, pl + (uint32_t)jN * sx8 + T.lo, cs8, (jN + k) & 1);
+    const rr_line  hSu = rr_load_line(y, plu + (uint32_t)jS * sx8 + T.lo, cs8, (jS + ku) & 1);
+    const rr_line  hNu = rr_load_line(y, plu + (uint32_t)jN * sx8 + T.lo, cs8, (jN + ku) & 1);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int      jc = min(max(2 * J - 1 + i, 0), jmax);
@@ -535,6 +540,8 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
       Dv[i] = Cv[i];
       Cv[i] = Uv[i];
     }
+    hS = hSu;
+    hN = hNu;
   }
   if (2 * K1 - 1 > klast && store) { // the top coarse plane has no plane above it
     out[0] = a.s0;
