@@ -244,6 +244,73 @@ __global__ __launch_bounds__(256) void st27_prolong_add_full_kernel(pmgk_st27_di
   x[p]            = x[p] + s;
 }
 
+// prolongation on a single device: thread = the coarse cell (I, J, K), i.e. the eight fine points (2I + dx, 2J + dy, 2K + dz)
+// that interpolate from its eight corners: four 16-byte coarse loads and four 16-byte read-modify-writes instead of eight
+// 8-byte loads and one 8-byte read-modify-write per fine point; the same sum in the same order for every point
+typedef double d2u8 __attribute__((ext_vector_type(2), aligned(8)));
+
+__global__ __launch_bounds__(256) void st27_prolong_add_cell_kernel(pmgk_st27_dims F, pmgk_st27_dims C, const double *__restrict__ ec, double *__restrict__ x)
+{
+  const int flat = blockIdx.x * 256 + threadIdx.x, J = flat / C.nx, I = flat - J * C.nx, K = blockIdx.z;
+  if (J >= C.ny) return;
+  const int32_t cnx = C.nx, cnxy = C.nx * C.ny, fnx = F.nx, fnxy = F.nx * F.ny;
+  const bool    x1 = 2 * I + 1 < F.nx, y1 = 2 * J + 1 < F.ny, z1 = 2 * K + 1 < F.nzg; // the odd point / line / plane of the cell exists
+  const int32_t cbase = (K + 1) * cnxy + J * cnx + I, fbase = (2 * K + 1) * fnxy + 2 * J * fnx + 2 * I;
+  // fine values first
+  double f[2][2][2];
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int32_t off = fbase + (dz && z1 ? fnxy : 0) + (dy && y1 ? fnx : 0);
+      if (x1) {
+        const d2u8 v = *reinterpret_cast<const d2u8 *>(x + off);
+        f[dz][dy][0] = v.x;
+        f[dz][dy][1] = v.y;
+      } else f[dz][dy][0] = f[dz][dy][1] = x[off];
+    }
+  double e[2][2][2]; // e[a][b][c] = coarse (K + a, J + b, I + c), clamped where the cell has no odd side (never used there)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq) {
+      const int32_t off = cbase + (a && z1 ? cnxy : 0) + (bq && y1 ? cnx : 0);
+      if (x1) {
+        const d2u8 v = *reinterpret_cast<const d2u8 *>(ec + off);
+        e[a][bq][0]  = v.x;
+        e[a][bq][1]  = v.y;
+      } else e[a][bq][0] = e[a][bq][1] = ec[off];
+    }
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      if ((dz && !z1) || (dy && !y1)) continue;
+      double out[2];
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        double sum = 0.0;
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz) {
+          const double wz = dz ? 0.5 : (cz ? 0.0 : 1.0);
+#pragma unroll
+          for (int by = 0; by < 2; ++by) {
+            const double wy = dy ? 0.5 : (by ? 0.0 : 1.0);
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+              const double wx = dx ? 0.5 : (ax ? 0.0 : 1.0);
+              sum             = sum + (wx * wy * wz) * e[cz & dz][by & dy][ax & dx];
+            }
+          }
+        }
+        out[dx] = f[dz][dy][dx] + sum;
+      }
+      const int32_t off = fbase + (dz ? fnxy : 0) + (dy ? fnx : 0);
+      if (x1) *reinterpret_cast<d2u8 *>(x + off) = d2u8{out[0], out[1]};
+      else x[off] = out[0];
+    }
+}
+
 inline bool st27_transfer_full_case(const pmgk_st27_dims *F, const pmgk_st27_dims *C)
 {
   static const int off = getenv("PMG_TRANSFER_GENERIC") != nullptr;
@@ -318,6 +385,12 @@ extern "C" int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims 
 extern "C" int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_dims *C, int kbegin, int kcount, const double *ec, double *x, void *stream)
 {
   if (kcount <= 0) return 0;
+  static const int cell = getenv("PMG_TRANSFER_CELL") ? atoi(getenv("PMG_TRANSFER_CELL")) : 1;
+  if (cell && st27_transfer_full_case(F, C) && F->kz0 == 0 && F->nz == F->nzg && C->kz0 == 0 && C->nz == C->nzg && kbegin == 0 && kcount == F->nz && C->nx == (F->nx + 1) / 2 && C->ny == (F->ny + 1) / 2 &&
+      C->nzg == (F->nzg + 1) / 2) {
+    hipLaunchKernelGGL(st27_prolong_add_cell_kernel, dim3((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, C->nzg), dim3(256), 0, (hipStream_t)stream, *F, *C, ec, x);
+    return launch_status();
+  }
   if (st27_transfer_full_case(F, C)) {
     hipLaunchKernelGGL(st27_prolong_add_full_kernel, dim3((unsigned)(((int64_t)F->nx * F->ny + 255) / 256), 1, kcount), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, ec, x);
     return launch_status();
