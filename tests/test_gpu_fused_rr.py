@@ -65,3 +65,45 @@ def test_vcycle_uses_the_fused_kernel_and_keeps_its_samples():
         env = dict(os.environ, PMG_GRID_FUSED_RR=flag)
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, check=True).stdout.strip())
     assert outs[0] == outs[1] and len(outs[0]) == 33 ** 3 * 16
+
+
+@pytest.mark.parametrize("dims,levels", [((5, 5, 5), 2), ((9, 9, 9), 3), ((17, 9, 33), 3), ((65, 33, 17), 3), ((253, 5, 9), 2), ((129, 65, 33), 4)])
+def test_quad_and_cell_prolongation_rows_match_the_oracle(dims, levels):
+    """q1_prolong_add_quad_kernel (grid level: a thread owns 2 x 2 fine lines) and st27_prolong_add_cell_kernel (class-
+    stencil levels: a thread owns a coarse cell) on cubes and boxes whose last line / plane pair is incomplete: every
+    row against the oracle's Q1 interpolation (reference: DMCreateInterpolation of the DMDA, src/pc_gamgmc.c:130-160)"""
+    import torch
+
+    from parmgmc_amd import MGMC, GridMCSOR
+
+    nx, ny, nz = dims
+    mg = MGMC(nx, ny, nz, 4.0, levels).setup()
+    top = levels - 1
+    g = GridMCSOR(nx, ny, nz, 4.0)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    cd = tuple((d + 1) // 2 for d in dims)
+    _, ldc, offc = mg.level_layout(top - 1)
+    cn = cd[0] * cd[1] * cd[2]
+    e = torch.zeros(ldc, dtype=torch.float64, device="cuda")
+    e[offc:offc + cn] = torch.randn(cn, dtype=torch.float64, device="cuda", generator=gen)
+    x0 = torch.randn(nx * ny * nz, dtype=torch.float64, device="cuda", generator=gen)
+    xc = g.to_cvec(x0)
+    mg.level_prolong_add(top, e, xc)
+    rows = np.arange(nx * ny * nz, dtype=np.int64)
+    want = O.q1_rows_prolong_add(dims, cd, rows, x0.cpu().numpy(), e[offc:offc + cn].cpu().numpy())
+    assert np.array_equal(g.from_cvec(xc).cpu().numpy(), want)
+    if levels >= 3:  # class-stencil level top-1 <- top-2
+        cd2 = tuple((d + 1) // 2 for d in cd)
+        kind, ld2, off2 = mg.level_layout(top - 2)
+        cn2 = cd2[0] * cd2[1] * cd2[2]
+        e2 = torch.zeros(ld2, dtype=torch.float64, device="cuda")
+        e2[off2:off2 + cn2] = torch.randn(cn2, dtype=torch.float64, device="cuda", generator=gen)
+        x1 = torch.randn(cn, dtype=torch.float64, device="cuda", generator=gen)
+        xp = torch.full((ldc,), 2.5, dtype=torch.float64, device="cuda")
+        xp[offc:offc + cn] = x1
+        mg.level_prolong_add(top - 1, e2, xp)
+        rows = np.arange(cn, dtype=np.int64)
+        want = O.q1_rows_prolong_add(cd, cd2, rows, x1.cpu().numpy(), e2[off2:off2 + cn2].cpu().numpy())
+        assert np.array_equal(xp[offc:offc + cn].cpu().numpy(), want)
+        assert float((xp[:offc] - 2.5).abs().max()) == 0.0 and float((xp[offc + cn:] - 2.5).abs().max()) == 0.0  # ghost planes untouched
+    mg.destroy()
