@@ -5,7 +5,7 @@ tag=$1; ctrs=$2; pat=${3:-pair}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmcdir_$tag
 rm -rf $out
-PMG_VC_ONLY=513 rocprofv3 --pmc $ctrs --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/tools/vcyclebench.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
+PMG_VC_ONLY=${VC_ONLY:-513} rocprofv3 --pmc $ctrs --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/tools/vcyclebench.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
 python3 - "$out" "$pat" > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.txt <<'PY'
 import csv, glob, re, sys
 from collections import defaultdict
