@@ -177,7 +177,8 @@ __device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, Zer
 }
 
 // one row of the neighbourhood from a vector in natural order behind one ghost plane; an absent line / plane is
-// replaced by the centre line (finite values that meet a zero coefficient)
+// replaced by the centre line (finite values that meet a zero coefficient).  kk: plane index inside the slab (global
+// plane - kz0; -1 and nz are the ghost planes of a z-slab)
 __device__ __forceinline__ void load_row(double (&r)[4], const double *vec, int nx, int ny, int xc0, int jj, int kk)
 {
   const double *row = vec + (int64_t)nx * (jj + (int64_t)ny * (kk + 1));
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
   const bool final_lane = lane >= HL && lane < HL + VALID; // lanes whose results are complete at the end of each stage
   const int  jt = 2 * PT * by;
   const bool hasD = C.k > 0, hasU = C.k < S.nzg - 1;
+  const int  kl = C.k - S.kz0; // plane inside the slab: addresses; C.k (global) keys the noise and the boundary classes
 
   // ---- stage A: the lines of the y-parity that is swept first --------------------------------------------------------
   {
@@ -243,13 +245,13 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
       C.j    = jA;
       C.line = (int64_t)nx * (jA + (int64_t)ny * C.k);
       const int jS = jA > 0 ? jA - 1 : jA, jN = jA < ny - 1 ? jA + 1 : jA;
-      const int64_t lrow = (int64_t)nx * (jA + (int64_t)ny * (C.k + 1)) + xc0;
+      const int64_t lrow = (int64_t)nx * (jA + (int64_t)ny * (kl + 1)) + xc0;
       const d2u     bv   = *reinterpret_cast<const d2u *>(b + lrow);
       const d2      bb   = {bv.x, bv.y};
       auto          rows = [&](int row, double (&r)[4]) {
         const int dz = row / 3 - 1, dy = row % 3 - 1;
         const bool okz = dz < 0 ? hasD : (dz > 0 ? hasU : true);
-        load_row(r, (dz != 0 && (okz || ZIN)) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jA), okz ? C.k + dz : C.k); // ZIN: y_in does not exist; an absent plane is replaced by y_other's centre plane (finite, zero coefficients)
+        load_row(r, (dz != 0 && (okz || ZIN)) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jA), okz ? kl + dz : kl); // ZIN: y_in does not exist; an absent plane is replaced by y_other's centre plane (finite, zero coefficients)
       };
       // stage A reads only old values: in-plane rows from y_in, the planes above / below from y_other
       auto zero = [&](int row) { return (row / 3 == 1) ? ZIN : ZOTHER; };
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
       C.j    = jB;
       C.line = (int64_t)nx * (jB + (int64_t)ny * C.k);
       const int jS = jB > 0 ? jB - 1 : jB, jN = jB < ny - 1 ? jB + 1 : jB;
-      const int64_t lrow = (int64_t)nx * (jB + (int64_t)ny * (C.k + 1)) + xc0;
+      const int64_t lrow = (int64_t)nx * (jB + (int64_t)ny * (kl + 1)) + xc0;
       const d2u     bv   = *reinterpret_cast<const d2u *>(b + lrow);
       const d2      bb   = {bv.x, bv.y};
       auto          rows = [&](int row, double (&r)[4]) {
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
           return;
         }
         const bool okz = dz < 0 ? hasD : (dz > 0 ? hasU : true);
-        load_row(r, (dz != 0 && (okz || ZIN)) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jB), okz ? C.k + dz : C.k);
+        load_row(r, (dz != 0 && (okz || ZIN)) ? y_other : y_in, nx, ny, xc0, dy < 0 ? jS : (dy > 0 ? jN : jB), okz ? kl + dz : kl);
       };
       // stage B: the own line is old (y_in), the lines above / below in this plane are stage A's new values (LDS)
       auto zero = [&](int row) { return (row / 3 == 1) ? (row == 4 && ZIN) : ZOTHER; };
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void st27_pair_residual_kernel(pmgk_st27 S, in
   const int nx = S.nx, ny = S.ny;
   // lanes 0 and 63 only supply their neighbours with the values beside the pairs: 62 pairs per wavefront
   const int npairs = (nx + 1) / 2;
-  const int p = 62 * bx - 1 + (int)threadIdx.x, j = 4 * by + __builtin_amdgcn_readfirstlane(threadIdx.y), k = bz;
+  const int p = 62 * bx - 1 + (int)threadIdx.x, j = 4 * by + __builtin_amdgcn_readfirstlane(threadIdx.y), k = S.kz0 + bz; // global plane
   if (j >= ny) return; // wave-uniform
   const int  x0   = 2 * min(max(p, 0), npairs - 1);
   const bool act0 = p >= 0 && p < npairs && threadIdx.x >= 1 && threadIdx.x <= 62, act1 = act0 && x0 + 1 < nx;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void st27_pair_residual_kernel(pmgk_st27 S, in
   for (int row = 0; row < 9; ++row) {
     const int dz = row / 3 - 1, dy = row % 3 - 1;
     double    r4[4];
-    load_row(r4, y, nx, ny, x0, dy < 0 ? jS : (dy > 0 ? jN : j), dz < 0 ? kD : (dz > 0 ? kU : k));
+    load_row(r4, y, nx, ny, x0, dy < 0 ? jS : (dy > 0 ? jN : j), (dz < 0 ? kD : (dz > 0 ? kU : k)) - S.kz0);
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
       const int e = 3 * row + dx + 1;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void st27_pair_residual_kernel(pmgk_st27 S, in
   }
   s0 = s0 + cf0[13] * c0;
   s1 = s1 + cf1[13] * c1;
-  const int64_t lrow = (int64_t)nx * (j + (int64_t)ny * (k + 1)) + x0;
+  const int64_t lrow = (int64_t)nx * (j + (int64_t)ny * (k - S.kz0 + 1)) + x0;
   const d2u     bv   = *reinterpret_cast<const d2u *>(b + lrow);
   if (act1) *reinterpret_cast<d2u *>(r + lrow) = d2u{bv.x - s0, bv.y - s1};
   else if (act0) r[lrow] = bv.x - s0;
@@ -349,51 +351,57 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 template <bool NOISY, bool BACKWARD, bool ZIN = false, bool ZOTHER = false>
 void launch_phase(const pmgk_st27 &S, int pz, double om1, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, const double *y_other, hipStream_t s)
 {
-  const int cz = (S.nzg - pz + 1) / 2; // planes of this parity
+  const int kfirst = S.kz0 + ((pz - S.kz0) & 1), cz = (S.kz0 + S.nz - kfirst + 1) / 2; // this slab's planes of the (global) parity pz
   if (cz <= 0) return;
   const int  npairs = (S.nx + 1) / 2;
   const int  nbx = (npairs + VALID - 1) / VALID, nby = (S.ny + 2 * PT - 1) / (2 * PT);
   const dim3 grid(xcd_grid(nbx, nby, cz)), block(64, PT + 1);
-  hipLaunchKernelGGL((st27_pair_phase_kernel<NOISY, BACKWARD, ZIN, ZOTHER>), grid, block, 0, s, S, nbx, nby, cz, pz, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y_in, y_out, y_other);
+  hipLaunchKernelGGL((st27_pair_phase_kernel<NOISY, BACKWARD, ZIN, ZOTHER>), grid, block, 0, s, S, nbx, nby, cz, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y_in, y_out, y_other);
 }
 
 } // namespace
 
-// One directional sweep OUT OF PLACE: y_out <- sweep(b, y_in); y_in is left untouched, the two must not overlap.
-// Single-device levels only (all planes owned: kz0 = 0, nz = nzg).
-extern "C" int pmgk_st27_sweep_pp(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, void *stream)
+// One z-parity phase of a directional sweep OUT OF PLACE (phase 0 reads the other parity's planes from y_in, phase 1 from
+// y_out, where phase 0 and -- on a z-slab -- the halo exchange behind it have put the new values); y_in is left
+// untouched, the two vectors must not overlap.  y_in == NULL: the sweep starts from a ZERO vector, which is neither stored
+// nor read (omega-independent: the old value enters as (1 - omega) * 0).
+extern "C" int pmgk_st27_sweep_pp_phase(const pmgk_st27 *S, int backward, int phase, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, void *stream)
 {
-  // y_in == NULL: the sweep starts from a ZERO vector, which is neither stored nor read (omega-independent: the old value
-  // enters as (1 - omega) * 0)
-  if (S->kz0 != 0 || S->nz != S->nzg || y_in == y_out) return 1;
-  const double om1 = 1. - omega;
-  hipStream_t  s   = (hipStream_t)stream;
-  const bool   zin = y_in == nullptr;
-  for (int phase = 0; phase < 2; ++phase) {
-    const int     pz    = backward ? 1 - phase : phase;
-    const double *other = phase == 0 ? y_in : y_out;
+  if (y_in == y_out || phase < 0 || phase > 1) return 1;
+  const double  om1 = 1. - omega;
+  hipStream_t   s   = (hipStream_t)stream;
+  const bool    zin = y_in == nullptr;
+  const int     pz    = backward ? 1 - phase : phase;
+  const double *other = phase == 0 ? y_in : y_out;
 #define PMG_PHASE(N, B) \
   do { \
     if (!zin) launch_phase<N, B, false, false>(*S, pz, om1, seed, sweep, b, y_in, y_out, other, s); \
     else if (phase == 0) launch_phase<N, B, true, true>(*S, pz, om1, seed, sweep, b, y_out, y_out, y_out, s); /* pointers unused: any valid address */ \
     else launch_phase<N, B, true, false>(*S, pz, om1, seed, sweep, b, y_out, y_out, other, s); \
   } while (0)
-    if (noisy) {
-      if (backward) PMG_PHASE(true, true);
-      else PMG_PHASE(true, false);
-    } else {
-      if (backward) PMG_PHASE(false, true);
-      else PMG_PHASE(false, false);
-    }
-#undef PMG_PHASE
+  if (noisy) {
+    if (backward) PMG_PHASE(true, true);
+    else PMG_PHASE(true, false);
+  } else {
+    if (backward) PMG_PHASE(false, true);
+    else PMG_PHASE(false, false);
   }
+#undef PMG_PHASE
   return launch_status();
+}
+
+// One directional sweep OUT OF PLACE on a level that lives on one device (all planes owned: kz0 = 0, nz = nzg): both phases
+extern "C" int pmgk_st27_sweep_pp(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, void *stream)
+{
+  if (S->kz0 != 0 || S->nz != S->nzg) return 1;
+  for (int phase = 0; phase < 2; ++phase)
+    if (pmgk_st27_sweep_pp_phase(S, backward, phase, omega, noisy, seed, sweep, b, y_in, y_out, stream)) return 1;
+  return 0;
 }
 
 extern "C" int pmgk_st27_residual_pair(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream)
 {
-  if (S->kz0 != 0 || S->nz != S->nzg) return 1;
-  if (S->nz <= 0) return 0;
+  if (S->nz <= 0) return 0; /* z-slabs too: the slab's planes, neighbours in the ghost planes */
   const int  npairs = (S->nx + 1) / 2;
   const int  nbx = (npairs + 61) / 62, nby = (S->ny + 3) / 4;
   const dim3 grid(xcd_grid(nbx, nby, S->nz)), block(64, 4);

@@ -115,6 +115,8 @@ int pmgk_st27_residual(const pmgk_st27 *S, const double *b, const double *y, dou
    y_in), two launches: one per z-parity phase, the four in-plane colours fused) and the residual with dense paired loads;
    same bits as the per-colour kernels */
 int pmgk_st27_sweep_pp(const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, void *stream);
+/* one z-parity phase of the out-of-place sweep, z-slabs included (the caller exchanges y_out's boundary planes between the phases) */
+int pmgk_st27_sweep_pp_phase(const pmgk_st27 *S, int backward, int phase, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, const double *y_in, double *y_out, void *stream);
 int pmgk_st27_residual_pair(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream);
 int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims *C, const double *r, double *bc, void *stream);
 /* fine planes kbegin .. kbegin+kcount-1 (global indices; may include the in-domain ghost planes of a slab) */

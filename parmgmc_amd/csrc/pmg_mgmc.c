@@ -509,6 +509,18 @@ static int st27_use_pair(const mg_level *Lv)
   return env && Lv->is_st27 && !Lv->distributed && Lv->kz0 == 0 && Lv->nzl == Lv->nz;
 }
 
+/* the same kernels on the z-slab of a distributed class-stencil level: one launch per z-parity phase instead of four, the
+   halo of the boundary planes behind each as before; PMG_ST27_PAIR_SLAB=0 keeps the per-colour kernels (same bits) */
+static int st27_use_pair_slab(const mg_level *Lv)
+{
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("PMG_ST27_PAIR_SLAB");
+    env           = e ? atoi(e) : 1;
+  }
+  return env && Lv->is_st27 && Lv->distributed;
+}
+
 /* one directional sweep of a class-stencil level on (b, *x): in place, or out of place into Lv->x2 followed by a swap of
    the two buffers when x is the level's own iterate */
 static pmg_status st27_one_sweep(mg_level *Lv, const pmgk_st27 *S, int backward, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, int x_is_zero, void *stream)
@@ -874,7 +886,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
     PMG_CALL(pmg_dev_alloc((void **)&Lv->b, sizeof(double) * (size_t)Lv->ld));
     PMG_CALL(pmg_dev_alloc((void **)&Lv->x, sizeof(double) * (size_t)Lv->ld));
     PMG_CALL(pmg_dev_alloc((void **)&Lv->r, sizeof(double) * (size_t)Lv->ld));
-    if (st27_use_pair(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld));
+    if (st27_use_pair(Lv) || st27_use_pair_slab(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld));
   }
   free(pos);
   PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)F->ld));
@@ -1200,7 +1212,7 @@ static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
     PMG_HIP(hipMemset(Lv->b, 0, sizeof(double) * (size_t)Lv->ld));
     PMG_HIP(hipMemset(Lv->x, 0, sizeof(double) * (size_t)Lv->ld));
     PMG_HIP(hipMemset(Lv->r, 0, sizeof(double) * (size_t)Lv->ld));
-    if (st27_use_pair(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld)); /* zero-filled: the ghost planes stay zero */
+    if (st27_use_pair(Lv) || st27_use_pair_slab(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld)); /* zero-filled: the ghost planes stay zero */
   }
   PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)F->ld));
   PMG_CALL(pmg_dev_alloc((void **)&h->b_lay, sizeof(double) * (size_t)F->ld));
@@ -1252,7 +1264,15 @@ static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, 
       const int     backward = ndir == 2 ? d : h->sweep_type == PMG_SOR_BACKWARD_SWEEP;
       const double *rhs      = Lv->b;
       if (Lv->lrc) PMG_CALL(pmg_lrc_rhs(Lv->lrc, Lv->b, seed, *ctr, &rhs, stream)); /* + B (sqrt(S) o eta), src/pc_mcgibbs.c:130-140 */
-      if (Lv->distributed) {
+      if (Lv->distributed && Lv->x2 && st27_use_pair_slab(Lv)) { /* out of place: x2 <- sweep(x), phase by phase, then the buffers swap */
+        PMG_KERNEL(pmgk_st27_sweep_pp_phase(&S, backward, 0, h->omega, 1, seed, *ctr, rhs, Lv->x, Lv->x2, stream));
+        PMG_CALL(halo_level(h, Lv, Lv->x2, stream));
+        PMG_KERNEL(pmgk_st27_sweep_pp_phase(&S, backward, 1, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, Lv->x2, stream));
+        PMG_CALL(halo_level(h, Lv, Lv->x2, stream));
+        double *t = Lv->x;
+        Lv->x     = Lv->x2;
+        Lv->x2    = t;
+      } else if (Lv->distributed) {
         PMG_KERNEL(pmgk_st27_sweep_phase(&S, backward, 0, h->omega, 1, seed, *ctr, rhs, Lv->x, stream));
         PMG_CALL(halo_level(h, Lv, Lv->x, stream));
         PMG_KERNEL(pmgk_st27_sweep_phase(&S, backward, 1, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, stream));
@@ -1378,7 +1398,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     }
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
     else if (Lv->is_st27) {
-      if (st27_use_pair(Lv)) PMG_KERNEL(pmgk_st27_residual_pair(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
+      if (st27_use_pair(Lv) || st27_use_pair_slab(Lv)) PMG_KERNEL(pmgk_st27_residual_pair(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
       else PMG_KERNEL(pmgk_st27_residual(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
       if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* PCMGSetResidual(..., As[l]), src/pc_gamgmc.c:194 */
     }
