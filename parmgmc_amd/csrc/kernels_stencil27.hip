@@ -249,20 +249,22 @@ __global__ __launch_bounds__(256) void st27_prolong_add_full_kernel(pmgk_st27_di
 // 8-byte loads and one 8-byte read-modify-write per fine point; the same sum in the same order for every point
 typedef double d2u8 __attribute__((ext_vector_type(2), aligned(8)));
 
-__global__ __launch_bounds__(256) void st27_prolong_add_cell_kernel(pmgk_st27_dims F, pmgk_st27_dims C, const double *__restrict__ ec, double *__restrict__ x)
+__global__ __launch_bounds__(256) void st27_prolong_add_cell_kernel(pmgk_st27_dims F, pmgk_st27_dims C, int gbeg, int gend, const double *__restrict__ ec, double *__restrict__ x)
 {
-  const int flat = blockIdx.x * 256 + threadIdx.x, J = flat / C.nx, I = flat - J * C.nx, K = blockIdx.z;
+  // global fine planes gbeg .. gend-1 (a z-slab: its planes and in-domain ghost planes); cell K = the planes 2K, 2K+1
+  const int flat = blockIdx.x * 256 + threadIdx.x, J = flat / C.nx, I = flat - J * C.nx, K = (gbeg >> 1) + (int)blockIdx.z;
   if (J >= C.ny) return;
   const int32_t cnx = C.nx, cnxy = C.nx * C.ny, fnx = F.nx, fnxy = F.nx * F.ny;
-  const bool    x1 = 2 * I + 1 < F.nx, y1 = 2 * J + 1 < F.ny, z1 = 2 * K + 1 < F.nzg; // the odd point / line / plane of the cell exists
-  const int32_t cbase = (K + 1) * cnxy + J * cnx + I, fbase = (2 * K + 1) * fnxy + 2 * J * fnx + 2 * I;
+  const bool    x1 = 2 * I + 1 < F.nx, y1 = 2 * J + 1 < F.ny; // the odd point / line of the cell exists
+  const bool    z0 = 2 * K >= gbeg && 2 * K < gend, z1 = 2 * K + 1 >= gbeg && 2 * K + 1 < gend; // its planes are in the range
+  const int32_t cbase = (K - C.kz0 + 1) * cnxy + J * cnx + I, fbase = (2 * K - F.kz0 + 1) * fnxy + 2 * J * fnx + 2 * I;
   // fine values first
   double f[2][2][2];
 #pragma unroll
   for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-      const int32_t off = fbase + (dz && z1 ? fnxy : 0) + (dy && y1 ? fnx : 0);
+      const int32_t off = fbase + ((dz ? z1 : !z0) ? fnxy : 0) + (dy && y1 ? fnx : 0); // a plane outside the range: the other one's address
       if (x1) {
         const d2u8 v = *reinterpret_cast<const d2u8 *>(x + off);
         f[dz][dy][0] = v.x;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void st27_prolong_add_cell_kernel(pmgk_st27_di
   for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-      if ((dz && !z1) || (dy && !y1)) continue;
+      if ((dz ? !z1 : !z0) || (dy && !y1)) continue;
       double out[2];
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
@@ -386,9 +388,9 @@ extern "C" int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_di
 {
   if (kcount <= 0) return 0;
   static const int cell = getenv("PMG_TRANSFER_CELL") ? atoi(getenv("PMG_TRANSFER_CELL")) : 1;
-  if (cell && st27_transfer_full_case(F, C) && F->kz0 == 0 && F->nz == F->nzg && C->kz0 == 0 && C->nz == C->nzg && kbegin == 0 && kcount == F->nz && C->nx == (F->nx + 1) / 2 && C->ny == (F->ny + 1) / 2 &&
-      C->nzg == (F->nzg + 1) / 2) {
-    hipLaunchKernelGGL(st27_prolong_add_cell_kernel, dim3((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, C->nzg), dim3(256), 0, (hipStream_t)stream, *F, *C, ec, x);
+  if (cell && st27_transfer_full_case(F, C) && C->nx == (F->nx + 1) / 2 && C->ny == (F->ny + 1) / 2 && C->nzg == (F->nzg + 1) / 2) {
+    const int gend = kbegin + kcount, ncell = ((gend - 1) >> 1) - (kbegin >> 1) + 1; /* kbegin: global plane */
+    hipLaunchKernelGGL(st27_prolong_add_cell_kernel, dim3((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, ncell), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, gend, ec, x);
     return launch_status();
   }
   if (st27_transfer_full_case(F, C)) {

@@ -324,21 +324,23 @@ __device__ __forceinline__ void prolong_line_pair(int oddx, int oddy, int oddz, 
   }
 }
 
-__global__ __launch_bounds__(256) void q1_prolong_add_quad_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int tplE, int csel, int xcd_runs, const double *__restrict__ ec, double *__restrict__ x)
+__global__ __launch_bounds__(256) void q1_prolong_add_quad_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int tplE, int csel, int xcd_runs, int gbeg, int gend, const double *__restrict__ ec, double *__restrict__ x)
 {
   // xcd_runs: gridDim.x is a multiple of 8 and XCD x (= blockIdx.x % 8 under round-robin dispatch; speed only) takes a contiguous run
   // of the line pairs of EVERY plane pair: the coarse rows two neighbouring line pairs or plane pairs share meet in one L2
   const int  lane = threadIdx.x & 63, npair = (L.ny + 1) / 2;
   const int  vb = xcd_runs ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   const int  flat = vb * 256 + threadIdx.x, Jp = flat / tplE, t = flat - Jp * tplE;
-  const int  K = (int)(csel >= 0 ? blockIdx.z : blockIdx.z >> 1), c = csel >= 0 ? csel : (int)(blockIdx.z & 1);
+  // global fine planes gbeg .. gend-1 (a z-slab: its planes and in-domain ghost planes); plane pair K = planes 2K, 2K+1
+  const int  K = (gbeg >> 1) + (int)(csel >= 0 ? blockIdx.z : blockIdx.z >> 1), c = csel >= 0 ? csel : (int)(blockIdx.z & 1);
   const bool live = Jp < npair;
   const int  J = live ? Jp : npair - 1;
   const int32_t cnx = C.nx, cnxy = C.nx * C.ny;
   const int     I0 = min(2 * t, cnx - 1);
   const bool    own_right = lane == 63 || t == tplE - 1;
-  const bool    line1 = 2 * J + 1 < L.ny, plane1 = 2 * K + 1 < L.nzg; // the odd line / plane of the quad exists
-  const int32_t base = (K + 1) * cnxy + J * cnx;
+  const bool    line1 = 2 * J + 1 < L.ny;                      // the odd line of the quad exists
+  const bool    plane0 = 2 * K >= gbeg && 2 * K < gend, plane1 = 2 * K + 1 >= gbeg && 2 * K + 1 < gend; // its planes are in the range
+  const int32_t base = (K - C.kz0 + 1) * cnxy + J * cnx;
   // fine values first: one round trip for everything
   d2t     v[2][2];
   double *px[2][2];
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void q1_prolong_add_quad_kernel(pmgk_grid_layo
   for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-      const int k = min(2 * K + dz, L.nzg - 1), j = min(2 * J + dy, L.ny - 1);
+      const int k = min(max(2 * K + dz, gbeg), gend - 1) - L.kz0, j = min(2 * J + dy, L.ny - 1); // k: plane inside the slab (-1, nz: ghosts)
       px[dz][dy]  = x + (int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + 2 * min(t, tplE - 1);
       v[dz][dy]   = *reinterpret_cast<d2t *>(px[dz][dy]);
     }
@@ -379,8 +381,8 @@ __global__ __launch_bounds__(256) void q1_prolong_add_quad_kernel(pmgk_grid_layo
   for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-      if ((dz && !plane1) || (dy && !line1)) continue;
-      const int  p = (c + dy + dz) & 1; // (c + j + k) & 1 with j = 2J + dy, k = 2K + dz
+      if ((dz ? !plane1 : !plane0) || (dy && !line1)) continue;
+      const int  p = (c + dy + dz) & 1; // (c + j + k) & 1 with j = 2J + dy, k = 2K + dz (global plane)
       const int  i0 = 4 * t + p;
       const bool act0 = i0 < L.nx, act1 = act0 && i0 + 2 < L.nx;
       if (!act0) continue;
@@ -436,12 +438,13 @@ extern "C" int pmgk_q1_prolong_add(const pmgk_grid_layout *L, const pmgk_st27_di
   if (transfer_full_case(L, C, cpos)) {
     static const int pair = getenv("PMG_TRANSFER_PAIR") ? atoi(getenv("PMG_TRANSFER_PAIR")) : 1;
     static const int quad = getenv("PMG_TRANSFER_QUAD") ? atoi(getenv("PMG_TRANSFER_QUAD")) : 1;
-    if (pair && quad && L->kz0 == 0 && L->nz == L->nzg && C->kz0 == 0 && kbegin == 0 && kcount == L->nz && C->ny == (L->ny + 1) / 2 && C->nzg == (L->nzg + 1) / 2) {
-      const int  npair = (L->ny + 1) / 2, nkp = (L->nzg + 1) / 2;
+    if (pair && quad && C->ny == (L->ny + 1) / 2 && C->nzg == (L->nzg + 1) / 2) {
+      const int  gbeg = L->kz0 + kbegin, gend = gbeg + kcount; // global planes
+      const int  npair = (L->ny + 1) / 2, nkp = ((gend - 1) >> 1) - (gbeg >> 1) + 1;
       const int64_t nb = ((int64_t)npair * tplE + 255) / 256;
       const int     runs = nb >= 64; // below that the padding to a multiple of 8 costs more than the shared rows bring (257^3: 35 vs 39 us)
       const dim3    qgrid((unsigned)(runs ? (nb + 7) / 8 * 8 : nb), 1, only_color >= 0 ? nkp : 2 * nkp);
-      hipLaunchKernelGGL(q1_prolong_add_quad_kernel, qgrid, dim3(256), 0, (hipStream_t)stream, *L, *C, tplE, only_color, runs, ec, x_cvec);
+      hipLaunchKernelGGL(q1_prolong_add_quad_kernel, qgrid, dim3(256), 0, (hipStream_t)stream, *L, *C, tplE, only_color, runs, gbeg, gend, ec, x_cvec);
       return launch_status();
     }
     if (pair) hipLaunchKernelGGL(q1_prolong_add_pair_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, kbegin, tplE, only_color, ec, x_cvec);
