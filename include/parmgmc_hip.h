@@ -276,6 +276,8 @@ pmg_status pmg_distmcsor_create(pmg_mcsor mc, pmg_dist dist, int32_t ncolors, co
    work between colours.  Collective.  Bit-identical to the single-process chain for any number of ranks. */
 pmg_status pmg_distmcsor_sample_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
 pmg_status pmg_distmcsor_apply_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int sweep_type, void *stream);
+/* refresh every ghost row of a layout vector from its owner (collective) */
+pmg_status pmg_distmcsor_refresh_layout(pmg_distmcsor h, double *v_lay, void *stream);
 pmg_status pmg_distmcsor_destroy(pmg_distmcsor *h);
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -310,6 +312,22 @@ pmg_status pmg_mgmc_create_hierarchy(int32_t levels, pmg_mgmc *mg);
 pmg_status pmg_mgmc_set_level_operator(pmg_mgmc mg, int32_t level, int32_t n, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host);
 /* interpolation from level-1 (ncols unknowns) to `level` (nrows unknowns), level >= 1 */
 pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc mg, int32_t level, int32_t nrows, int32_t ncols, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host);
+/* Caller-supplied hierarchy distributed by ROW BLOCKS over the ranks of `dist` (any pmg_dist object: only its transport is
+   used), the reference's PCGAMGMC on a MATMPIAIJ (src/pc_gamgmc.c:157-223 with MCSORApply_MPIAIJ, src/mc_sor.c:298-381, as
+   the level sampler).  Level 0 (exact sampler) is passed whole on every rank and factored redundantly; its right-hand side
+   is all-gathered by the row blocks coarse_starts[0 .. nranks].  A level l >= 1 is this rank's rows in LOCAL numbering
+   (pmg_mgmc_set_level_operator: owned rows in global order with their entries in global CSR order, then one identity row
+   per ghost = every row of another rank that this rank's operator, restriction or the finer level's interpolation reads)
+   plus pmg_mgmc_set_level_rowblock: global row of local row 0, number of owned rows, a globally valid distance-1 colouring
+   of the owned rows, and the ghost-update plan of pmg_distmcsor_create with LOCAL ROW indices in place of layout
+   positions.  pmg_mgmc_set_level_interpolation(l) then takes the owned rows of P_l with columns in the local numbering of
+   level l-1 (global for l-1 = 0) and pmg_mgmc_set_level_restriction(l) the rows of P_l^T this rank owns on level l-1,
+   columns in the local numbering of level l, entries by ascending global fine row.  pmg_mgmc_sample's vectors have one
+   entry per local row of the finest level (ghost entries ignored / undefined).  Same bits as the single-device chain of
+   pmg_mgmc_create_hierarchy with the same colouring.  PMG_ERR_SUP: low-rank updates, Gibbs coarse solver. */
+pmg_status pmg_mgmc_set_rowblock_transport(pmg_mgmc mg, pmg_dist dist, const int64_t *coarse_starts);
+pmg_status pmg_mgmc_set_level_rowblock(pmg_mgmc mg, int32_t level, int64_t row0, int32_t nowned, int32_t ncolors, const int32_t *colors_owned, const int64_t *send_ptr, const int32_t *send_rows, const int64_t *counts, const int64_t *recv_ptr, const int32_t *recv_src, const int32_t *recv_rows);
+pmg_status pmg_mgmc_set_level_restriction(pmg_mgmc mg, int32_t level, int32_t nrows, int32_t ncols, const int32_t *rowptr, const int32_t *colidx, const double *vals);
 /* both for either PetscInt width (idx_width = 32 | 64) */
 pmg_status pmg_mgmc_set_level_operator_idx(pmg_mgmc mg, int32_t level, int64_t n, const void *rowptr_host, const void *colidx_host, const double *vals_host, int idx_width);
 pmg_status pmg_mgmc_set_level_interpolation_idx(pmg_mgmc mg, int32_t level, int64_t nrows, int64_t ncols, const void *rowptr_host, const void *colidx_host, const double *vals_host, int idx_width);

@@ -167,6 +167,10 @@ _sig = {
     "pmg_mgmc_level_sweep": (_int, [_vp, _i32, _int, _int, _u64, _u64, _vp, _vp, _vp]),
     "pmg_mgmc_level_residual": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "pmg_mgmc_level_restrict": (_int, [_vp, _i32, _vp, _vp, _vp]),
+    "pmg_mgmc_set_rowblock_transport": (_int, [_vp, _vp, _vp]),
+    "pmg_mgmc_set_level_rowblock": (_int, [_vp, _i32, C.c_int64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmg_mgmc_set_level_restriction": (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "pmg_distmcsor_refresh_layout": (_int, [_vp, _vp, _vp]),
     "pmg_mgmc_level_residual_restrict": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "pmg_mgmc_level_prolong_add": (_int, [_vp, _i32, _vp, _vp, _vp]),
     "pmg_initialize": (_int, []),

@@ -155,6 +155,15 @@ static pmg_status distmcsor_sweeps(pmg_distmcsor h, const double *b, double *y, 
   return PMG_SUCCESS;
 }
 
+/* every ghost row of a layout vector from its owner (all colours' updates): the vector may be any level vector -- a
+   residual whose restriction reads other ranks' rows, an iterate after an interpolation.  Collective. */
+pmg_status pmg_distmcsor_refresh_layout(pmg_distmcsor h, double *v_lay, void *stream)
+{
+  PMG_CHECK(h && v_lay, PMG_ERR_ARG_NULL, "null argument");
+  for (int32_t c = 0; c < h->ncolors; ++c) PMG_CALL(distmcsor_update(h, c, v_lay, stream));
+  return PMG_SUCCESS;
+}
+
 /* `its` samples of the mcgibbs / sorgibbs chain on layout vectors (b, y: my rows filled; the ghost entries of y are
    refreshed here).  Collective: every rank makes the same call. */
 pmg_status pmg_distmcsor_sample_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)

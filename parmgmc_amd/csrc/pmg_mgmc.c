@@ -60,6 +60,16 @@ typedef struct {
   /* caller-supplied hierarchy (borrowed host CSR until set-up) */
   hcsr A_user, P_user;
   int32_t *A_rp_own, *A_ci_own, *P_rp_own, *P_ci_own; /* 32-bit copies of 64-bit PetscInt arrays, freed after set-up */
+  /* ROW BLOCK of a distributed hierarchy (pmg_mgmc_set_level_rowblock): A_user is this rank's rows in LOCAL numbering --
+     owned rows first, then one identity row per ghost (every row of another rank that this rank's operator, restriction
+     or the finer level's interpolation reads); the plan lists are host copies until set-up builds `dm` from them */
+  int           rb;
+  int32_t       rb_nowned, rb_ncolors;
+  int64_t       rb_row0;
+  int32_t      *rb_colors, *rb_send_idx, *rb_recv_src, *rb_recv_idx;
+  int64_t      *rb_send_ptr, *rb_recv_ptr, *rb_counts;
+  hcsr          R_user; /* rows of the restriction INTO the next coarser level that this rank owns there (borrowed) */
+  pmg_distmcsor dm;
 } mg_level;
 
 struct pmg_mgmc_s {
@@ -82,6 +92,9 @@ struct pmg_mgmc_s {
   int32_t   rank, nranks;
   int32_t  *cuts;
   int32_t   n_io; /* length of the caller's fine-level vectors (the owned planes) */
+  /* row-block distributed caller-supplied hierarchy: transport (borrowed) and the row blocks of the replicated coarsest level */
+  pmg_dist  rb_dist;
+  int64_t  *rb_c0_starts;
 };
 
 typedef struct {
@@ -415,7 +428,86 @@ pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc h, int32_t level, int32_t n
   return PMG_SUCCESS;
 }
 
-/* the two calls above for either PetscInt width: idx_width = sizeof(PetscInt) * 8 */
+/* ---- caller-supplied hierarchy distributed by ROW BLOCKS (the reference runs PCGAMGMC on any MATMPIAIJ,
+   src/pc_gamgmc.c:157-223; MCSORApply_MPIAIJ src/mc_sor.c:298-381 is the level sampler) --------------------------------
+   Every rank describes ITS rows:
+   * level 0 (coarsest, exact sampler): the whole matrix on every rank (pmg_mgmc_set_level_operator) -- it is factored
+     redundantly, the restricted right-hand side is all-gathered by the row blocks `coarse_starts`;
+   * level l >= 1: pmg_mgmc_set_level_operator with the rank's rows in LOCAL numbering (owned rows 0 .. nowned-1 in the
+     order of the global rows row0 .. row0+nowned-1, entries in the order of the global CSR row, then one identity row
+     per ghost), and pmg_mgmc_set_level_rowblock with a globally valid distance-1 colouring of the owned rows and the
+     ghost-update plan of pmg_distmcsor_create in LOCAL ROW indices;
+   * pmg_mgmc_set_level_interpolation(l): the owned rows of P_l, columns in the local numbering of level l-1 (global
+     indices for l-1 = 0); pmg_mgmc_set_level_restriction(l): the rows of R_l = P_l^T that this rank owns on level l-1,
+     columns in the local numbering of level l, entries by ascending global fine row (the order of a transposition).
+   Noise is keyed on global rows and every row keeps its global entry order: the chain is the single-device chain of
+   pmg_mgmc_create_hierarchy bit for bit.  Low-rank updates are not supported on row blocks. */
+pmg_status pmg_mgmc_set_rowblock_transport(pmg_mgmc h, pmg_dist dist, const int64_t *coarse_starts)
+{
+  PMG_CHECK(h && dist && coarse_starts, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(h->user_hier && !h->is_setup, PMG_ERR_ARG_WRONGSTATE, "row blocks belong to pmg_mgmc_create_hierarchy, before set-up");
+  int32_t rank, nranks;
+  PMG_CALL(pmg_dist_get_info(dist, &rank, &nranks, NULL));
+  PMG_CHECK(nranks >= 1 && nranks <= 64, PMG_ERR_ARG_OUTOFRANGE, "%d ranks", nranks);
+  free(h->rb_c0_starts);
+  h->rb_c0_starts = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nranks + 1));
+  PMG_CHECK(h->rb_c0_starts, PMG_ERR_MEM, "out of host memory");
+  memcpy(h->rb_c0_starts, coarse_starts, sizeof(int64_t) * ((size_t)nranks + 1));
+  for (int r = 0; r < nranks; ++r) PMG_CHECK(coarse_starts[r] <= coarse_starts[r + 1], PMG_ERR_ARG_WRONG, "coarse row blocks must be ascending");
+  PMG_CHECK(coarse_starts[0] == 0, PMG_ERR_ARG_WRONG, "coarse row blocks must start at 0");
+  h->rb_dist = dist;
+  h->rank    = rank;
+  h->nranks  = nranks;
+  return PMG_SUCCESS;
+}
+
+static void *dup_bytes(const void *src, size_t bytes)
+{
+  void *p = malloc(bytes ? bytes : 1);
+  if (p && bytes) memcpy(p, src, bytes);
+  return p;
+}
+
+pmg_status pmg_mgmc_set_level_rowblock(pmg_mgmc h, int32_t level, int64_t row0, int32_t nowned, int32_t ncolors, const int32_t *colors_owned, const int64_t *send_ptr, const int32_t *send_idx, const int64_t *counts, const int64_t *recv_ptr, const int32_t *recv_src, const int32_t *recv_idx)
+{
+  PMG_CHECK(h && colors_owned && send_ptr && counts && recv_ptr, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(h->user_hier && !h->is_setup && h->rb_dist, PMG_ERR_ARG_WRONGSTATE, "call pmg_mgmc_set_rowblock_transport first, before set-up");
+  PMG_CHECK(level >= 1 && level < h->nlevels, PMG_ERR_ARG_OUTOFRANGE, "level %d (the coarsest level is replicated)", level);
+  PMG_CHECK(row0 >= 0 && nowned >= 0 && ncolors >= 1, PMG_ERR_ARG_OUTOFRANGE, "row0 %lld, %d owned rows, %d colours", (long long)row0, nowned, ncolors);
+  mg_level    *Lv = &h->lv[level];
+  const size_t nc1 = (size_t)ncolors + 1, ns = (size_t)send_ptr[ncolors], nr = (size_t)recv_ptr[ncolors];
+  PMG_CHECK((ns == 0 || send_idx) && (nr == 0 || (recv_src && recv_idx)), PMG_ERR_ARG_NULL, "null index list");
+  free(Lv->rb_colors), free(Lv->rb_send_ptr), free(Lv->rb_recv_ptr), free(Lv->rb_counts), free(Lv->rb_send_idx), free(Lv->rb_recv_src), free(Lv->rb_recv_idx);
+  Lv->rb_colors   = (int32_t *)dup_bytes(colors_owned, sizeof(int32_t) * (size_t)nowned);
+  Lv->rb_send_ptr = (int64_t *)dup_bytes(send_ptr, sizeof(int64_t) * nc1);
+  Lv->rb_recv_ptr = (int64_t *)dup_bytes(recv_ptr, sizeof(int64_t) * nc1);
+  Lv->rb_counts   = (int64_t *)dup_bytes(counts, sizeof(int64_t) * (size_t)ncolors * (size_t)h->nranks);
+  Lv->rb_send_idx = (int32_t *)dup_bytes(send_idx, sizeof(int32_t) * ns);
+  Lv->rb_recv_src = (int32_t *)dup_bytes(recv_src, sizeof(int32_t) * nr);
+  Lv->rb_recv_idx = (int32_t *)dup_bytes(recv_idx, sizeof(int32_t) * nr);
+  PMG_CHECK(Lv->rb_colors && Lv->rb_send_ptr && Lv->rb_recv_ptr && Lv->rb_counts && Lv->rb_send_idx && Lv->rb_recv_src && Lv->rb_recv_idx, PMG_ERR_MEM, "out of host memory");
+  Lv->rb         = 1;
+  Lv->rb_row0    = row0;
+  Lv->rb_nowned  = nowned;
+  Lv->rb_ncolors = ncolors;
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_set_level_restriction(pmg_mgmc h, int32_t level, int32_t nrows, int32_t ncols, const int32_t *rowptr, const int32_t *colidx, const double *vals)
+{
+  PMG_CHECK(h && rowptr && colidx && vals, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(h->user_hier && !h->is_setup, PMG_ERR_ARG_WRONGSTATE, "restrictions belong to pmg_mgmc_create_hierarchy, before set-up");
+  PMG_CHECK(level >= 1 && level < h->nlevels, PMG_ERR_ARG_OUTOFRANGE, "level %d", level);
+  mg_level *Lv  = &h->lv[level];
+  Lv->R_user.nr = nrows;
+  Lv->R_user.nc = ncols;
+  Lv->R_user.rp = (int32_t *)rowptr; /* borrowed, only read */
+  Lv->R_user.ci = (int32_t *)colidx;
+  Lv->R_user.v  = (double *)vals;
+  return PMG_SUCCESS;
+}
+
+/* pmg_mgmc_set_level_operator / _interpolation for either PetscInt width: idx_width = sizeof(PetscInt) * 8 */
 pmg_status pmg_mgmc_set_level_operator_idx(pmg_mgmc h, int32_t level, int64_t n, const void *rowptr, const void *colidx, const double *vals, int idx_width)
 {
   PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
@@ -676,12 +768,28 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
   for (int l = 0; l <= top; ++l) {
     mg_level *Lv = &h->lv[l];
     PMG_CHECK(Lv->A_user.rp, PMG_ERR_ARG_WRONGSTATE, "level %d has no operator", l);
-    PMG_CHECK(l == 0 || (Lv->P_user.rp && Lv->P_user.nr == Lv->n && Lv->P_user.nc == h->lv[l - 1].n), PMG_ERR_ARG_SIZ, "interpolation of level %d missing or of the wrong shape", l);
+    if (h->rb_dist) { /* row blocks: every level above the coarsest is one, the coarsest is replicated and sampled exactly */
+      PMG_CHECK(l == 0 ? !Lv->rb : Lv->rb, PMG_ERR_ARG_WRONGSTATE, "row-block hierarchy: level %d %s", l, l == 0 ? "is the replicated coarsest level" : "has no row block (pmg_mgmc_set_level_rowblock)");
+      PMG_CHECK(h->coarse_type == 0 && !h->lrc_k, PMG_ERR_SUP, "row-block hierarchies: exact coarse sampler, no low-rank update");
+      PMG_CHECK(l == 0 || (Lv->P_user.rp && Lv->R_user.rp && Lv->P_user.nr == Lv->rb_nowned && Lv->P_user.nc == h->lv[l - 1].n && Lv->R_user.nc == Lv->n), PMG_ERR_ARG_SIZ, "level %d: interpolation rows = owned rows, its columns and the restriction's in local numbering", l);
+      PMG_CHECK(l == 0 || Lv->R_user.nr == (l == 1 ? (int32_t)(h->rb_c0_starts[h->rank + 1] - h->rb_c0_starts[h->rank]) : h->lv[l - 1].rb_nowned), PMG_ERR_ARG_SIZ, "level %d: the restriction has one row per owned row of level %d", l, l - 1);
+      PMG_CHECK(l > 0 || h->rb_c0_starts[h->nranks] == Lv->n, PMG_ERR_ARG_SIZ, "the coarse row blocks cover %lld rows, the coarsest level has %d", (long long)h->rb_c0_starts[h->nranks], Lv->n);
+    } else
+      PMG_CHECK(l == 0 || (Lv->P_user.rp && Lv->P_user.nr == Lv->n && Lv->P_user.nc == h->lv[l - 1].n), PMG_ERR_ARG_SIZ, "interpolation of level %d missing or of the wrong shape", l);
     pos[l] = (int32_t *)malloc(sizeof(int32_t) * (size_t)Lv->n);
     PMG_CHECK(pos[l], PMG_ERR_MEM, "out of host memory");
     if (l > 0 || h->coarse_type == 1) {
       PMG_CALL(pmg_mcsor_create_csr(Lv->n, Lv->A_user.rp, Lv->A_user.ci, Lv->A_user.v, &Lv->mc));
-      PMG_CALL(pmg_mcsor_set_coloring(Lv->mc, PMG_COLORING_GREEDY, NULL));
+      if (Lv->rb) { /* the caller's global colouring on the owned rows, the ghost rows in a colour of their own that is never swept */
+        PMG_CHECK(Lv->rb_nowned <= Lv->n, PMG_ERR_ARG_SIZ, "level %d: %d owned rows of %d local rows", l, Lv->rb_nowned, Lv->n);
+        int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)Lv->n);
+        PMG_CHECK(col, PMG_ERR_MEM, "out of host memory");
+        for (int32_t r = 0; r < Lv->n; ++r) col[r] = r < Lv->rb_nowned ? Lv->rb_colors[r] : Lv->rb_ncolors;
+        pmg_status st = pmg_mcsor_set_coloring(Lv->mc, PMG_COLORING_USER, col);
+        free(col);
+        PMG_CALL(st);
+        PMG_CALL(pmg_mcsor_set_noise_row_offset(Lv->mc, Lv->rb_row0));
+      } else PMG_CALL(pmg_mcsor_set_coloring(Lv->mc, PMG_COLORING_GREEDY, NULL));
       PMG_CALL(pmg_mcsor_set_omega(Lv->mc, h->omega));
       PMG_CALL(pmg_mcsor_set_sweep_type(Lv->mc, h->sweep_type));
       PMG_CALL(pmg_mcsor_setup(Lv->mc));
@@ -689,6 +797,23 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
       PMG_CALL(pmg_mcsor_layout_len(Lv->mc, &ld32));
       Lv->ld = ld32;
       PMG_CALL(pmg_mcsor_get_layout(Lv->mc, pos[l]));
+      if (Lv->rb) { /* the ghost-update plan in layout positions */
+        const int64_t ns = Lv->rb_send_ptr[Lv->rb_ncolors], nr = Lv->rb_recv_ptr[Lv->rb_ncolors];
+        int32_t      *sp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ns + 1)), *rp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nr + 1));
+        pmg_status    st = (sp && rp) ? PMG_SUCCESS : pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+        for (int64_t q = 0; q < ns && !st; ++q) {
+          if (Lv->rb_send_idx[q] < 0 || Lv->rb_send_idx[q] >= Lv->rb_nowned) st = pmg_set_error(PMG_ERR_ARG_OUTOFRANGE, __FILE__, __LINE__, "level %d: send row %d is not an owned row", l, Lv->rb_send_idx[q]);
+          else sp[q] = pos[l][Lv->rb_send_idx[q]];
+        }
+        for (int64_t q = 0; q < nr && !st; ++q) {
+          if (Lv->rb_recv_idx[q] < Lv->rb_nowned || Lv->rb_recv_idx[q] >= Lv->n) st = pmg_set_error(PMG_ERR_ARG_OUTOFRANGE, __FILE__, __LINE__, "level %d: receive row %d is not a ghost row", l, Lv->rb_recv_idx[q]);
+          else rp[q] = pos[l][Lv->rb_recv_idx[q]];
+        }
+        if (!st) st = pmg_distmcsor_create(Lv->mc, h->rb_dist, Lv->rb_ncolors, Lv->rb_send_ptr, sp, Lv->rb_counts, Lv->rb_recv_ptr, Lv->rb_recv_src, rp, &Lv->dm);
+        free(sp);
+        free(rp);
+        PMG_CALL(st);
+      }
     } else {
       Lv->ld = Lv->n;
       for (int32_t q = 0; q < Lv->n; ++q) pos[l][q] = q;
@@ -701,7 +826,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     mg_level *U = &h->lv[l];
     hcsr      R;
     memset(&R, 0, sizeof R);
-    PMG_CALL(hcsr_transpose(&U->P_user, &R));
+    if (!U->rb) PMG_CALL(hcsr_transpose(&U->P_user, &R));
     if (h->lrc_k) { /* B_{l-1} = P_l^T B_l, src/pc_gamgmc.c:177-178 */
       mg_level *Cc = &h->lv[l - 1];
       double   *Bc = NULL;
@@ -712,9 +837,11 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
       if (l - 1 == 0 && h->coarse_type == 0) PMG_CALL(pmg_chol_create_csr_lowrank(Cc->n, Cc->A_user.rp, Cc->A_user.ci, Cc->A_user.v, h->lrc_k, Bcur, h->lrc_S, &h->chol));
     }
     U->P_nrows = U->P_user.nr;
-    U->R_nrows = R.nr;
+    U->R_nrows = U->rb ? U->R_user.nr : R.nr;
     PMG_CALL(upload_transfer(&U->P_user, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
-    PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    if (U->rb) /* the caller's rows of P^T: owned rows of level l-1 (on the replicated coarsest level: this rank's block of the global rows) */
+      PMG_CALL(upload_transfer(&U->R_user, pos[l - 1] + (l == 1 ? h->rb_c0_starts[h->rank] : 0), pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    else PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
     hcsr_free(&R);
   }
   if (Bcur != h->lrc_B) free(Bcur);
@@ -723,6 +850,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     mg_level *Lv = &h->lv[l];
     memset(&Lv->A_user, 0, sizeof Lv->A_user); /* borrowed arrays are released */
     memset(&Lv->P_user, 0, sizeof Lv->P_user);
+    memset(&Lv->R_user, 0, sizeof Lv->R_user);
     free(Lv->A_rp_own);
     free(Lv->A_ci_own);
     free(Lv->P_rp_own);
@@ -735,6 +863,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
   free(pos);
   PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)h->lv[top].ld));
   PMG_CALL(pmg_dev_alloc((void **)&h->b_lay, sizeof(double) * (size_t)h->lv[top].ld));
+  h->n_io     = h->lv[top].n; /* the caller's vectors: one entry per (local) row of the finest level */
   h->is_setup = 1;
   return PMG_SUCCESS;
 }
@@ -1311,6 +1440,7 @@ static pmg_status mg_smooth(pmg_mgmc h, int l, uint64_t seed, uint64_t *ctr, voi
   } else if (Lv->is_grid && h->dist) PMG_CALL(pmg_dist_sample_cvec(h->dist, Lv->b, Lv->x, h->nu, h->scaled, h->sweep_type, level_seed(seed, l), *ctr, ctr, stream)); /* leaves the ghost planes current */
   else if (Lv->is_grid) PMG_CALL(pmg_grid_sample_cvec(Lv->g, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
   else if (Lv->is_st27) PMG_CALL(st27_sample(h, Lv, h->nu, level_seed(seed, l), ctr, stream));
+  else if (Lv->dm) PMG_CALL(pmg_distmcsor_sample_layout(Lv->dm, Lv->b, Lv->x, h->nu, h->scaled, h->sweep_type, level_seed(seed, l), *ctr, ctr, stream)); /* row block: refreshes the ghost rows first, leaves them current */
   else PMG_CALL(pmg_mcsor_sample_layout(Lv->mc, Lv->b, Lv->x, h->nu, h->scaled, level_seed(seed, l), *ctr, ctr, stream));
   return PMG_SUCCESS;
 }
@@ -1339,7 +1469,13 @@ static pmg_status mg_restrict(pmg_mgmc h, int l, double *r_fine, double *b_coars
     const pmgk_st27_dims FD = level_dims(Lv);
     PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, r_fine, bc, stream));
   } else {
+    if (Lv->dm) PMG_CALL(pmg_distmcsor_refresh_layout(Lv->dm, r_fine, stream)); /* row block: the rows of P^T read r on other ranks' rows */
     PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, r_fine, b_coarse, 0, stream));
+    if (Lv->dm && l == 1) { /* the replicated coarsest level: every rank needs the whole right-hand side */
+      int64_t cnts[64];
+      for (int r = 0; r < h->nranks; ++r) cnts[r] = h->rb_c0_starts[r + 1] - h->rb_c0_starts[r];
+      PMG_CALL(pmg_dist_allgather(h->rb_dist, b_coarse, h->rb_c0_starts, cnts, stream));
+    }
   }
   if (fold) {
     int64_t offs[64], cnts[64];
@@ -1449,6 +1585,7 @@ pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32
   PMG_CALL(lvl_to_layout(F, b_nat, h->b_lay, stream));
   PMG_CALL(lvl_to_layout(F, y_nat, h->y_lay, stream));
   if (h->correction_form && F->distributed) PMG_CALL(halo_level(h, F, h->y_lay, stream)); /* the outer residual reads the ghost planes of y */
+  if (h->correction_form && F->dm) PMG_CALL(pmg_distmcsor_refresh_layout(F->dm, h->y_lay, stream)); /* ... the ghost rows of a row block */
   for (int32_t it = 0; it < its; ++it) {
     if (!h->correction_form) {
       /* The cycle run IN PLACE on (b, y): a stationary linear sweep satisfies S(b, y) = y + S(b - A y, 0) with the
@@ -1591,7 +1728,9 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
   for (int l = 0; l < h->nlevels; ++l) {
     mg_level *Lv = &h->lv[l];
     if (h->own_grid || !Lv->is_grid) pmg_grid_destroy(&Lv->g);
+    pmg_distmcsor_destroy(&Lv->dm);
     pmg_mcsor_destroy(&Lv->mc);
+    free(Lv->rb_colors), free(Lv->rb_send_ptr), free(Lv->rb_recv_ptr), free(Lv->rb_counts), free(Lv->rb_send_idx), free(Lv->rb_recv_src), free(Lv->rb_recv_idx);
     pmg_dev_free(Lv->b);
     pmg_dev_free(Lv->x);
     pmg_dev_free(Lv->r);

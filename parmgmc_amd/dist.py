@@ -582,3 +582,225 @@ class DistMCSOR:
             self.destroy()
         except Exception:
             pass
+
+
+def rowblock_plan(ci_global, row0: int, row1: int, n_global: int, colors_owned, ncolors: int, extra_ghosts, rank: int, world: int, group=None):
+    """Ghost set and per-colour ghost-update plan of one row block (what MatCreateScatters builds per colour in the
+    reference, src/mc_sor.c:152-214; here de-duplicated per ghost row and laid out for ONE all-gather per colour).
+
+    ci_global: the global column indices of this rank's rows; extra_ghosts: further global rows of other ranks whose
+    values this rank reads (restriction / interpolation columns).  Returns (ghosts, plan) with ghosts = sorted global
+    ids (local row nloc + q) and plan = dict(send_ptr, send_rows, counts, recv_ptr, recv_src, recv_rows): local OWNED rows
+    this rank contributes per colour (by ascending global row), the ranks' block lengths, and for every ghost row the
+    index of its value in the colour's gather buffer (blocks in rank order).  Collective over `group` (host objects)."""
+    import numpy as np
+    import torch.distributed as dist
+
+    ci = np.asarray(ci_global, np.int64)
+    nloc = row1 - row0
+    off = ci[(ci < row0) | (ci >= row1)]
+    extra = np.asarray(extra_ghosts, np.int64)
+    extra = extra[(extra < row0) | (extra >= row1)]
+    ghosts = np.unique(np.concatenate([off, extra]))
+    ranges = [None] * world
+    dist.all_gather_object(ranges, (row0, row1), group=group)
+    starts = np.array([r[0] for r in ranges] + [n_global])
+    assert all(ranges[r][1] == starts[r + 1] for r in range(world)), "row blocks must tile the rows in rank order"
+    owner = np.searchsorted(starts, ghosts, side="right") - 1
+    want = [ghosts[owner == p] for p in range(world)]  # global rows I need from rank p
+    asked = [None] * world
+    dist.all_gather_object(asked, want, group=group)  # asked[q][p] = rows rank q needs from rank p
+    mycol = np.asarray(colors_owned, np.int64)
+    assert len(mycol) == nloc and (nloc == 0 or (mycol.min() >= 0 and mycol.max() < ncolors))
+    others = [np.asarray(asked[q][rank], np.int64) for q in range(world) if q != rank]
+    needed = np.unique(np.concatenate(others)) if others else np.zeros(0, np.int64)  # my rows that another rank reads
+    send_lists = [needed[mycol[needed - row0] == c] for c in range(ncolors)]  # sorted global rows, by colour
+    all_lists = [None] * world
+    dist.all_gather_object(all_lists, send_lists, group=group)
+    counts = np.array([[len(all_lists[r][c]) for r in range(world)] for c in range(ncolors)], np.int64).reshape(ncolors, world)
+    offs = np.concatenate([np.zeros((ncolors, 1), np.int64), np.cumsum(counts, axis=1)[:, :-1]], axis=1)
+    send_ptr = np.concatenate([[0], np.cumsum([len(l) for l in send_lists])]).astype(np.int64)
+    send_rows = (np.concatenate(send_lists) - row0 if send_ptr[-1] else np.zeros(0)).astype(np.int32)
+    rsrc, rrow, rptr = [], [], [0]
+    for c in range(ncolors):
+        for p in range(world):
+            if p == rank or not len(want[p]):
+                continue
+            lst = np.asarray(all_lists[p][c], np.int64)
+            if not len(lst):
+                continue
+            k = np.searchsorted(lst, want[p])
+            hit = (k < len(lst)) & (lst[np.minimum(k, len(lst) - 1)] == want[p])  # my ghosts owned by p that have colour c
+            rsrc.append(offs[c, p] + k[hit])
+            rrow.append(nloc + np.searchsorted(ghosts, want[p][hit]))
+        rptr.append(sum(len(a) for a in rsrc))
+    plan = dict(send_ptr=send_ptr, send_rows=send_rows, counts=np.ascontiguousarray(counts),
+                recv_ptr=np.asarray(rptr, np.int64),
+                recv_src=(np.concatenate(rsrc) if rsrc else np.zeros(0)).astype(np.int32),
+                recv_rows=(np.concatenate(rrow) if rrow else np.zeros(0)).astype(np.int32))
+    assert plan["recv_ptr"][-1] == len(ghosts), "every ghost row is owned by exactly one rank and has exactly one colour"
+    return ghosts, plan
+
+
+class DistAIJMGMC:
+    """MGMC sampler on a caller-supplied hierarchy of assembled MATAIJ matrices distributed by ROW BLOCKS, one rank per
+    device: the reference's PCGAMGMC on a MATMPIAIJ (src/pc_gamgmc.c:157-223; level sampler MCSORApply_MPIAIJ,
+    src/mc_sor.c:298-381).  `operators[l]` = global CSR triple of level l (0 = coarsest), `interpolations[l]` (l >= 1) =
+    global CSR triple of the prolongation from level l-1 to level l -- what MGMC.from_hierarchy takes, available on every
+    rank; `starts[l]` = the world+1 row-block boundaries of level l (default: equal blocks).  Every rank keeps its rows of
+    the levels >= 1 (plus one ghost row per row of another rank that its operator, restriction or the finer level's
+    interpolation reads) and the whole coarsest level, which is factored redundantly.  The whole sample loop -- colour
+    sweeps, ghost updates, residuals, transfers, coarse solve -- runs in C (pmg_mgmc.c) on the stream; this class only
+    slices the matrices and builds the ghost plans (host set-up, collective).  Bit-identical to MGMC.from_hierarchy."""
+
+    def __init__(self, operators, interpolations, rank: int, world: int, group=None, transport=None, starts=None):
+        import ctypes as C
+        import os
+
+        import numpy as np
+        import scipy.sparse as sp
+        import torch
+        import torch.distributed as dist
+
+        from .capi import check, lib
+        from .wrappers import MCSOR
+
+        self.rank, self.world, self.group = rank, world, group
+        L = len(operators)
+        assert L >= 2 and len(interpolations) == L
+        A = [sp.csr_matrix((np.asarray(v, np.float64), np.asarray(ci, np.int64), np.asarray(rp, np.int64)), shape=(len(rp) - 1, len(rp) - 1)) for rp, ci, v in operators]
+        P = [None] + [sp.csr_matrix((np.asarray(interpolations[l][2], np.float64), np.asarray(interpolations[l][1], np.int64), np.asarray(interpolations[l][0], np.int64)), shape=(A[l].shape[0], A[l - 1].shape[0])) for l in range(1, L)]
+        n = [a.shape[0] for a in A]
+        if starts is None:
+            starts = [np.linspace(0, n[l], world + 1).astype(np.int64) for l in range(L)]
+        self.starts = [np.asarray(s, np.int64) for s in starts]
+        r0 = [int(s[rank]) for s in self.starts]
+        r1 = [int(s[rank + 1]) for s in self.starts]
+        # --- transport: the generic all-gather of pmg_dist.c ("ipc" peer stores or RCCL), agreed between the ranks
+        on_gpu = dist.get_backend(group) == "nccl"
+        want_tr = transport or os.environ.get("PMG_DIST_TRANSPORT")
+        self._drv, self.transport = None, None
+        for cand in ([want_tr] if want_tr else ["ipc", "rccl"]):
+            ok, err, drv = 1, None, None
+            try:
+                drv = IpcSlabDriver(None, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(None, rank, world, group=group)
+            except Exception as e:  # noqa: BLE001
+                ok, err = 0, e
+            flag = torch.tensor([ok], device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 1:
+                self._drv, self.transport = drv, cand
+                break
+            if drv is not None:
+                drv.destroy()
+            if rank == 0:
+                print(f"[parmgmc_amd] transport '{cand}' unavailable for the row-block hierarchy ({err if err else 'on another rank'})", flush=True)
+        if self._drv is None:
+            raise RuntimeError("DistAIJMGMC needs the 'ipc' or 'rccl' transport of the HIP library")
+        # --- per level: global colouring (the library's first-fit rule, as MGMC.from_hierarchy applies it), ghost sets, plans
+        self._keep = []
+        self._h = C.c_void_p()
+        check(lib.pmg_mgmc_create_hierarchy(L, C.byref(self._h)))
+        a0 = A[0].tocsr()
+        a0.sort_indices()
+        rp0, ci0, v0 = a0.indptr.astype(np.int32), a0.indices.astype(np.int32), np.ascontiguousarray(a0.data)
+        self._keep.append((rp0, ci0, v0))
+        check(lib.pmg_mgmc_set_level_operator(self._h, 0, n[0], rp0.ctypes.data, ci0.ctypes.data, v0.ctypes.data))
+        cs = np.ascontiguousarray(self.starts[0], np.int64)
+        self._keep.append(cs)
+        check(lib.pmg_mgmc_set_rowblock_transport(self._h, self._drv._h, cs.ctypes.data))
+        R = [None] + [P[l].T.tocsr() for l in range(1, L)]  # rows of P^T, entries by ascending fine row
+        for m in R[1:]:
+            m.sort_indices()
+        ghosts, nloc = [None] * L, [r1[l] - r0[l] for l in range(L)]
+        local_of = [None] * L  # global row -> local row of this rank (owned, then ghosts), -1 elsewhere; level 0: identity
+        local_of[0] = np.arange(n[0], dtype=np.int64)
+        for l in range(1, L):
+            Al = A[l]
+            mc = MCSOR(Al.indptr.astype(np.int32), Al.indices.astype(np.int32), Al.data).setup()  # the global colouring, on the device's host code
+            col, ncol = mc.get_coloring(), mc.get_num_colors()
+            mc.destroy()
+            mine = Al[r0[l]:r1[l]]
+            extra = [R[l][r0[l - 1]:r1[l - 1]].indices.astype(np.int64)]  # fine rows my restriction rows read
+            if l + 1 < L:
+                extra.append(P[l + 1][r0[l + 1]:r1[l + 1]].indices.astype(np.int64))  # rows of this level the finer level's interpolation reads
+            ghosts[l], plan = rowblock_plan(mine.indices, r0[l], r1[l], n[l], col[r0[l]:r1[l]], ncol, np.concatenate(extra), rank, world, group)
+            ng = len(ghosts[l])
+            lo = np.full(n[l], -1, np.int64)
+            lo[r0[l]:r1[l]] = np.arange(nloc[l])
+            lo[ghosts[l]] = nloc[l] + np.arange(ng)
+            local_of[l] = lo
+            # local operator: my rows (entries in the order of the global CSR row) + one identity row per ghost
+            rp = np.concatenate([mine.indptr, mine.indptr[-1] + 1 + np.arange(ng)]).astype(np.int32)
+            ci = np.concatenate([lo[mine.indices], nloc[l] + np.arange(ng)]).astype(np.int32)
+            assert ci.min(initial=0) >= 0
+            v = np.concatenate([mine.data, np.ones(ng)])
+            cols = np.ascontiguousarray(col[r0[l]:r1[l]], np.int32)
+            self._keep += [rp, ci, v, cols, plan]
+            check(lib.pmg_mgmc_set_level_operator(self._h, l, nloc[l] + ng, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+            check(lib.pmg_mgmc_set_level_rowblock(self._h, l, r0[l], nloc[l], ncol, cols.ctypes.data, plan["send_ptr"].ctypes.data, plan["send_rows"].ctypes.data, plan["counts"].ctypes.data,
+                                                  plan["recv_ptr"].ctypes.data, plan["recv_src"].ctypes.data, plan["recv_rows"].ctypes.data))
+        for l in range(1, L):
+            pm = P[l][r0[l]:r1[l]]  # my rows of P_l (entries in the caller's order), columns -> local numbering of level l-1
+            prp, pci, pv = pm.indptr.astype(np.int32), local_of[l - 1][pm.indices].astype(np.int32), np.ascontiguousarray(pm.data)
+            rm = R[l][r0[l - 1]:r1[l - 1]]  # the rows of P_l^T I own on level l-1, columns -> local numbering of level l
+            rrp, rci, rv = rm.indptr.astype(np.int32), local_of[l][rm.indices].astype(np.int32), np.ascontiguousarray(rm.data)
+            assert pci.min(initial=0) >= 0 and rci.min(initial=0) >= 0, "a transfer reads a row that is neither owned nor a ghost"
+            ncl = n[0] if l == 1 else nloc[l - 1] + len(ghosts[l - 1])
+            self._keep += [prp, pci, pv, rrp, rci, rv]
+            check(lib.pmg_mgmc_set_level_interpolation(self._h, l, nloc[l], ncl, prp.ctypes.data, pci.ctypes.data, pv.ctypes.data))
+            check(lib.pmg_mgmc_set_level_restriction(self._h, l, len(rrp) - 1, nloc[l] + len(ghosts[l]), rrp.ctypes.data, rci.ctypes.data, rv.ctypes.data))
+        self.n_owned, self.n_local = nloc[L - 1], nloc[L - 1] + len(ghosts[L - 1])
+        self.row_range = (r0[L - 1], r1[L - 1])
+        self.levels = L
+
+    def set_smoother(self, scaled: bool, omega: float = 1.0, sweep_type: int = SOR_FORWARD_SWEEP, its: int = 1):
+        from .capi import check, lib
+
+        check(lib.pmg_mgmc_set_smoother(self._h, int(scaled), omega, sweep_type, its))
+
+    def set_correction_form(self, literal: bool):
+        from .capi import check, lib
+
+        check(lib.pmg_mgmc_set_correction_form(self._h, int(literal)))
+
+    def setup(self):
+        from .capi import check, lib
+
+        err = None
+        try:
+            check(lib.pmg_mgmc_setup(self._h))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        _all_ok(err, self.group, "row-block hierarchy set-up")
+        return self
+
+    def sample(self, b_owned, y_owned, its: int, seed: int, counter0: int = 0, guesszero: bool = False) -> int:
+        """`its` samples; b_owned, y_owned: this rank's rows of the finest level (device tensors, y updated in place)"""
+        import ctypes as C
+
+        import torch
+
+        from .capi import check, lib
+        from .wrappers import _ptr, _stream
+
+        b = torch.zeros(self.n_local, dtype=torch.float64, device="cuda")
+        y = torch.zeros(self.n_local, dtype=torch.float64, device="cuda")
+        b[: self.n_owned] = b_owned
+        y[: self.n_owned] = y_owned
+        out = C.c_uint64()
+        check(lib.pmg_mgmc_sample(self._h, _ptr(b), _ptr(y), its, int(guesszero), seed, counter0, C.byref(out), None, None, _stream()))
+        y_owned.copy_(y[: self.n_owned])
+        return out.value
+
+    def destroy(self):
+        import ctypes as C
+
+        from .capi import lib
+
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.pmg_mgmc_destroy(C.byref(self._h))
+            self._h = None
+        if getattr(self, "_drv", None) is not None:
+            self._drv.destroy()  # collective: disconnect, barrier, destroy
+            self._drv = None
