@@ -279,6 +279,46 @@ def mgmc_dist_secondary(rank: int, world: int, transport, share: bool, n: int = 
     return res
 
 
+def unstructured_dist_secondary(rank: int, world: int, transport, share: bool, refine: int = 5, its: int = 20) -> dict:
+    """Secondary line (BASELINE config 4's matrix on N GPUs): the MGMC chain on the aggregation hierarchy of the refined
+    lshape.msh P1 matrix, every level above the coarsest distributed by ROW BLOCKS (parmgmc_amd.dist.DistAIJMGMC: the
+    reference's PCGAMGMC on a MATMPIAIJ), the same matrix for every N (strong scaling).  Collective.  Not the headline."""
+    import torch
+    import torch.distributed as dist
+
+    from parmgmc_amd.dist import DistAIJMGMC
+    from parmgmc_amd.unstructured import assemble_p1, build_hierarchy, read_gmsh41_triangles, refine_uniform
+
+    t0 = time.perf_counter()
+    xy, tris = read_gmsh41_triangles(ROOT / "tests" / "golden" / "lshape.msh")
+    for _ in range(refine):
+        xy, tris = refine_uniform(xy, tris)
+    ops, ps = build_hierarchy(assemble_p1(xy, tris, 1.0), coarse_max=2000)
+    mg = DistAIJMGMC(ops, ps, rank, world, transport=transport)
+    mg.set_smoother(True, 1.0, 1, 1)
+    mg.setup()
+    setup_s = time.perf_counter() - t0
+    b = torch.ones(mg.n_owned, dtype=torch.float64, device="cuda")
+    y = torch.zeros(mg.n_owned, dtype=torch.float64, device="cuda")
+    ctr = mg.sample(b, y, 3, seed=0xCAFE)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t1 = time.perf_counter()
+    mg.sample(b, y, its, seed=0xCAFE, counter0=ctr)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t1
+    dev = "cpu" if share else "cuda"
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    fin = torch.tensor([1.0 if bool(torch.isfinite(y).all().item()) else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+    ms = float(t.item()) / its * 1e3
+    res = {"workload": f"lshape.msh refined {refine}x: {len(ops[-1][0]) - 1} rows, aggregation hierarchy {[len(o[0]) - 1 for o in ops]}, row blocks over {world} ranks, strong scaling", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "n_gpus": world, "transport": mg.transport, "setup_s": setup_s, "finite": bool(fin.item() == 1.0)}
+    mg.destroy()
+    return res
+
+
 def spawn_ranks(n: int, argv: list) -> int:
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: start N fresh ranks (one per GPU) as a child
     `python -m torch.distributed.run` BEFORE this process imports torch or touches a GPU, pass their output through
@@ -570,9 +610,15 @@ def main() -> None:
             sec = mgmc_dist_secondary(rank, world, used_transport if used_transport in ("ipc", "rccl") else None, share, args.mgmc_n, args.mgmc_levels)
             if rank == 0:
                 out["secondary_mgmc_dist"] = sec
+            if world > 1 and tr2:
+                sec = unstructured_dist_secondary(rank, world, tr2, share)
+                if rank == 0:
+                    out["secondary_unstructured_dist"] = sec
         except Exception as e:  # noqa: BLE001
             if rank == 0:
-                out["secondary_mgmc_dist"] = {"error": f"{type(e).__name__}: {e}"}
+                out.setdefault("secondary_mgmc_dist", {"error": f"{type(e).__name__}: {e}"})
+                if "secondary_mgmc_dist" in out and "error" not in out["secondary_mgmc_dist"]:
+                    out["secondary_unstructured_dist"] = {"error": f"{type(e).__name__}: {e}"}
     dog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, n)
