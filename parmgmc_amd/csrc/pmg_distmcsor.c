@@ -31,6 +31,11 @@ struct pmg_distmcsor_s {
   int32_t *send_pos_dev, *recv_src_dev, *recv_pos_dev;
   double  *gbuf;
   int64_t  gcap;
+  /* all colours at once (a refresh of every ghost row): rank r's block = its colour blocks one after the other, so the
+     send list is the concatenation that is already stored; all_src[q] = index of ghost q's value in that buffer.
+     all_tot = -1: the combined block exceeds the transport's capacity, refresh colour by colour */
+  int64_t *all_off, *all_cnt, all_tot;
+  int32_t *all_src_dev;
 };
 
 pmg_status pmg_distmcsor_destroy(pmg_distmcsor *hp)
@@ -42,6 +47,9 @@ pmg_status pmg_distmcsor_destroy(pmg_distmcsor *hp)
   free(h->goff);
   free(h->gcnt);
   free(h->gtot);
+  free(h->all_off);
+  free(h->all_cnt);
+  pmg_dev_free(h->all_src_dev);
   pmg_dev_free(h->send_pos_dev);
   pmg_dev_free(h->recv_src_dev);
   pmg_dev_free(h->recv_pos_dev);
@@ -111,6 +119,39 @@ pmg_status pmg_distmcsor_create(pmg_mcsor mc, pmg_dist dist, int32_t ncolors, co
   if (!st) st = pmg_dev_upload((void **)&h->send_pos_dev, send_pos, sizeof(int32_t) * (size_t)ns);
   if (!st) st = pmg_dev_upload((void **)&h->recv_src_dev, recv_src, sizeof(int32_t) * (size_t)nr);
   if (!st) st = pmg_dev_upload((void **)&h->recv_pos_dev, recv_pos, sizeof(int32_t) * (size_t)nr);
+  /* the combined plan */
+  int32_t *all_src = NULL;
+  if (!st) {
+    const size_t nrk = (size_t)(h->nranks > 0 ? h->nranks : 1);
+    h->all_off = (int64_t *)calloc(nrk, sizeof(int64_t));
+    h->all_cnt = (int64_t *)calloc(nrk, sizeof(int64_t));
+    int64_t *pre = (int64_t *)calloc(ncr ? ncr : 1, sizeof(int64_t)); /* pre[c][r]: rank r's values of the colours before c */
+    all_src      = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nr > 0 ? nr : 1));
+    if (!h->all_off || !h->all_cnt || !pre || !all_src) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+    if (!st) {
+      for (int32_t c = 0; c < ncolors; ++c)
+        for (int32_t r = 0; r < h->nranks; ++r) {
+          pre[(size_t)c * h->nranks + r] = h->all_cnt[r];
+          h->all_cnt[r] += counts[(size_t)c * h->nranks + r];
+        }
+      int64_t off = 0;
+      for (int32_t r = 0; r < h->nranks; ++r) {
+        h->all_off[r] = off;
+        off += h->all_cnt[r];
+      }
+      h->all_tot = off <= h->gcap && off < ((int64_t)1 << 31) ? off : -1;
+      for (int32_t c = 0; c < ncolors && h->all_tot >= 0; ++c)
+        for (int64_t q = recv_ptr[c]; q < recv_ptr[c + 1]; ++q) {
+          int32_t r = 0; /* the rank whose block of colour c holds the value */
+          while (r + 1 < h->nranks && recv_src[q] >= h->goff[(size_t)c * h->nranks + r + 1]) ++r;
+          all_src[q] = (int32_t)(h->all_off[r] + pre[(size_t)c * h->nranks + r] + (recv_src[q] - h->goff[(size_t)c * h->nranks + r]));
+        }
+    }
+    free(pre);
+  }
+  if (!st && h->all_tot >= 0) st = pmg_dev_upload((void **)&h->all_src_dev, all_src, sizeof(int32_t) * (size_t)nr);
+  free(all_src);
+  if (!st && h->all_tot > maxtot) maxtot = h->all_tot;
   if (!st) st = pmg_dev_alloc((void **)&h->gbuf, sizeof(double) * (size_t)(maxtot > 0 ? maxtot : 1));
   if (st) {
     pmg_distmcsor_destroy(&h);
@@ -132,12 +173,30 @@ static pmg_status distmcsor_update(pmg_distmcsor h, int32_t c, double *y, void *
   return PMG_SUCCESS;
 }
 
+/* every ghost row: ONE all-gather of all colours' boundary values where the transport can carry them, else colour by colour */
+static pmg_status distmcsor_refresh(pmg_distmcsor h, double *y, void *stream)
+{
+  if (h->nranks == 1) return PMG_SUCCESS;
+  static int by_colour = -1; /* PMG_DISTMCSOR_REFRESH_BY_COLOUR=1: the colour-by-colour form (same values) */
+  if (by_colour < 0) by_colour = getenv("PMG_DISTMCSOR_REFRESH_BY_COLOUR") != NULL;
+  if (h->all_tot < 0 || by_colour) {
+    for (int32_t c = 0; c < h->ncolors; ++c) PMG_CALL(distmcsor_update(h, c, y, stream));
+    return PMG_SUCCESS;
+  }
+  if (h->all_tot == 0) return PMG_SUCCESS;
+  const int64_t ns = h->send_ptr[h->ncolors], nr = h->recv_ptr[h->ncolors];
+  if (ns > 0) PMG_KERNEL(pmgk_gather_idx(ns, h->send_pos_dev, y, h->gbuf + h->all_off[h->rank], stream));
+  PMG_CALL(pmg_dist_allgather(h->dist, h->gbuf, h->all_off, h->all_cnt, stream));
+  if (nr > 0) PMG_KERNEL(pmgk_scatter_idx(nr, h->all_src_dev, h->recv_pos_dev, h->gbuf, y, stream));
+  return PMG_SUCCESS;
+}
+
 static pmg_status distmcsor_sweeps(pmg_distmcsor h, const double *b, double *y, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
 {
   PMG_CHECK(h && b && y, PMG_ERR_ARG_NULL, "null argument");
   PMG_CHECK(its >= 0, PMG_ERR_ARG_OUTOFRANGE, "its = %d", its);
   PMG_CHECK(pmg_sweep_type_ok(sweep_type), PMG_ERR_SUP, "Only forward, backward and symmetric sweep supported");
-  for (int32_t c = 0; c < h->ncolors; ++c) PMG_CALL(distmcsor_update(h, c, y, stream)); /* the caller's y has no ghost values yet */
+  PMG_CALL(distmcsor_refresh(h, y, stream)); /* the caller's y has no ghost values yet */
   uint64_t ctr = counter0;
   for (int32_t it = 0; it < its; ++it) {
     const int ndir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
@@ -160,8 +219,7 @@ static pmg_status distmcsor_sweeps(pmg_distmcsor h, const double *b, double *y, 
 pmg_status pmg_distmcsor_refresh_layout(pmg_distmcsor h, double *v_lay, void *stream)
 {
   PMG_CHECK(h && v_lay, PMG_ERR_ARG_NULL, "null argument");
-  for (int32_t c = 0; c < h->ncolors; ++c) PMG_CALL(distmcsor_update(h, c, v_lay, stream));
-  return PMG_SUCCESS;
+  return distmcsor_refresh(h, v_lay, stream);
 }
 
 /* `its` samples of the mcgibbs / sorgibbs chain on layout vectors (b, y: my rows filled; the ghost entries of y are
