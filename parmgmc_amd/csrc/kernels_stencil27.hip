@@ -218,32 +218,6 @@ __global__ __launch_bounds__(256) void st27_restrict_full_kernel(pmgk_st27_dims 
   bc[I + (int64_t)C.nx * (J + (int64_t)C.ny * (K - C.kz0 + 1))] = s;
 }
 
-__global__ __launch_bounds__(256) void st27_prolong_add_full_kernel(pmgk_st27_dims F, pmgk_st27_dims C, int kbegin, const double *__restrict__ ec, double *__restrict__ x)
-{
-  const int flat = blockIdx.x * 256 + threadIdx.x, j = flat / F.nx, i = flat - j * F.nx, k = kbegin + blockIdx.z;
-  if (j >= F.ny) return;
-  const int32_t cnx = C.nx, cnxy = C.nx * C.ny;
-  const int     oddx = i & 1, oddy = j & 1, oddz = k & 1;
-  const int32_t base = ((k >> 1) - C.kz0 + 1) * cnxy + (j >> 1) * cnx + (i >> 1);
-  double        s    = 0.0;
-#pragma unroll
-  for (int cz = 0; cz < 2; ++cz) {
-    const double wz = oddz ? 0.5 : (cz ? 0.0 : 1.0);
-#pragma unroll
-    for (int by = 0; by < 2; ++by) {
-      const double wy = oddy ? 0.5 : (by ? 0.0 : 1.0);
-#pragma unroll
-      for (int ax = 0; ax < 2; ++ax) {
-        const double  wx  = oddx ? 0.5 : (ax ? 0.0 : 1.0);
-        const int32_t off = base + (cz & oddz) * cnxy + (by & oddy) * cnx + (ax & oddx);
-        s                 = s + (wx * wy * wz) * *at_bytes(ec, 8u * (uint32_t)off);
-      }
-    }
-  }
-  const int64_t p = i + (int64_t)F.nx * (j + (int64_t)F.ny * (k - F.kz0 + 1));
-  x[p]            = x[p] + s;
-}
-
 // prolongation on a single device: thread = the coarse cell (I, J, K), i.e. the eight fine points (2I + dx, 2J + dy, 2K + dz)
 // that interpolate from its eight corners: four 16-byte coarse loads and four 16-byte read-modify-writes instead of eight
 // 8-byte loads and one 8-byte read-modify-write per fine point; the same sum in the same order for every point
@@ -387,14 +361,9 @@ extern "C" int pmgk_st27_restrict(const pmgk_st27_dims *F, const pmgk_st27_dims 
 extern "C" int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_dims *C, int kbegin, int kcount, const double *ec, double *x, void *stream)
 {
   if (kcount <= 0) return 0;
-  static const int cell = getenv("PMG_TRANSFER_CELL") ? atoi(getenv("PMG_TRANSFER_CELL")) : 1;
-  if (cell && st27_transfer_full_case(F, C) && C->nx == (F->nx + 1) / 2 && C->ny == (F->ny + 1) / 2 && C->nzg == (F->nzg + 1) / 2) {
+  if (st27_transfer_full_case(F, C) && C->nx == (F->nx + 1) / 2 && C->ny == (F->ny + 1) / 2 && C->nzg == (F->nzg + 1) / 2) {
     const int gend = kbegin + kcount, ncell = ((gend - 1) >> 1) - (kbegin >> 1) + 1; /* kbegin: global plane */
     hipLaunchKernelGGL(st27_prolong_add_cell_kernel, dim3((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, ncell), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, gend, ec, x);
-    return launch_status();
-  }
-  if (st27_transfer_full_case(F, C)) {
-    hipLaunchKernelGGL(st27_prolong_add_full_kernel, dim3((unsigned)(((int64_t)F->nx * F->ny + 255) / 256), 1, kcount), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, ec, x);
     return launch_status();
   }
   hipLaunchKernelGGL(st27_prolong_add_kernel, dim3((unsigned)(((int64_t)F->nx * F->ny + 255) / 256), 1, kcount), dim3(256), 0, (hipStream_t)stream, *F, *C, kbegin, ec, x);

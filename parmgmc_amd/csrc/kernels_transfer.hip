@@ -49,45 +49,6 @@ __global__ __launch_bounds__(256) void q1_restrict_kernel(pmgk_grid_layout L, pm
   bc[coarse_pos(C, cpos, I, J, K)] = s;
 }
 
-__device__ __forceinline__ const double *at_bytes(const double *base, uint32_t byte_off) { return reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off); }
-
-// the common case (all three directions refined, coarse level in plane-padded natural storage, fine cvec < 4 GiB):
-// no branch per fine point -- a point outside the domain is read at the centre with weight 0 (s + 0*r = s, so the sum
-// is the same bits), 32-bit offsets from the scalar vector base, all 27 loads in flight at once
-__global__ __launch_bounds__(256) void q1_restrict_full_kernel(pmgk_grid_layout L, pmgk_st27_dims C, const double *__restrict__ r, double *__restrict__ bc)
-{
-  const int flat = blockIdx.x * blockDim.x + threadIdx.x, J = flat / C.nx, I = flat - J * C.nx, K = C.kz0 + blockIdx.z;
-  if (J >= C.ny) return;
-  const int32_t sx = (int32_t)L.sx, sp = (int32_t)L.sp, cs = (int32_t)L.cs;
-  const int     fi = 2 * I, fj = 2 * J, fk = 2 * K;
-  double        s  = 0.0;
-#pragma unroll
-  for (int dz = -1; dz <= 1; ++dz) {
-    const int     kg   = fk + dz;
-    const bool    okz  = (unsigned)kg < (unsigned)L.nzg;
-    const int     kk   = okz ? kg : fk;
-    const int32_t zoff = (kk - L.kz0 + 1) * sp;
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int     j    = fj + dy;
-      const bool    oky  = (unsigned)j < (unsigned)L.ny;
-      const int     jj   = oky ? j : fj;
-      const int32_t yoff = zoff + jj * sx;
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int     i   = fi + dx;
-        const bool    okx = (unsigned)i < (unsigned)L.nx;
-        const int     ii  = okx ? i : fi;
-        const int32_t off = yoff + (ii >> 1) + (((ii + jj + kk) & 1) ? cs : 0);
-        const double  w0  = (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0);
-        const double  w   = (okx && oky && okz) ? w0 : 0.0;
-        s                 = s + w * *at_bytes(r, 8u * (uint32_t)off);
-      }
-    }
-  }
-  bc[I + (int64_t)C.nx * (J + (int64_t)C.ny * (K - C.kz0 + 1))] = s;
-}
-
 // x += P e_c on the colour-partitioned fine vector: thread = two consecutive same-colour points (one 16-byte
 // read-modify-write), blocks of 64 lanes x 4 lines like the sweep; up to 8 coarse reads per point (L2-resident),
 // summed in ascending coarse index.
@@ -118,44 +79,6 @@ __global__ __launch_bounds__(256) void q1_prolong_add_kernel(pmgk_grid_layout L,
   d2t           v  = *reinterpret_cast<d2t *>(px);
   v.x              = v.x + q1_interp_point(i0, j, k + L.kz0, C, rx, ry, rz, cpos, ec);
   if (i1 < L.nx) v.y = v.y + q1_interp_point(i1, j, k + L.kz0, C, rx, ry, rz, cpos, ec);
-  *reinterpret_cast<d2t *>(px) = v;
-}
-
-// same common case for the prolongation: always 8 coarse reads per point, the ones a non-midpoint direction does not
-// use carry weight 0 (and address the used one, so no extra traffic); the two points of a thread share their parities
-__global__ __launch_bounds__(256) void q1_prolong_add_full_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int kbegin, int tplE, int csel, const double *__restrict__ ec, double *__restrict__ x)
-{
-  const int flat = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x, j = flat / tplE, t = flat - j * tplE;
-  const int k = kbegin + (int)(csel >= 0 ? blockIdx.z : blockIdx.z >> 1), c = csel >= 0 ? csel : (int)(blockIdx.z & 1); // k: local plane, -1 / nz = ghosts
-  if (j >= L.ny || 2 * t >= L.sx) return;
-  const int kg = k + L.kz0, p = (c + j + kg) & 1;
-  const int i0 = 4 * t + p, i1 = i0 + 2;
-  if (i0 >= L.nx) return;
-  double       *px = x + (int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)j * L.sx + 2 * t;
-  d2t           v  = *reinterpret_cast<d2t *>(px);
-  const int32_t cnx = C.nx, cnxy = C.nx * C.ny;
-  const int     oddx = p, oddy = j & 1, oddz = kg & 1;
-  const int32_t base = ((kg >> 1) - C.kz0 + 1) * cnxy + (j >> 1) * cnx + (i0 >> 1);
-  const int32_t second = i1 < L.nx ? 1 : 0; // the second point's coarse neighbours lie one to the right
-  double        s0 = 0.0, s1 = 0.0;
-#pragma unroll
-  for (int cz = 0; cz < 2; ++cz) {
-    const double wz = oddz ? 0.5 : (cz ? 0.0 : 1.0);
-#pragma unroll
-    for (int by = 0; by < 2; ++by) {
-      const double wy = oddy ? 0.5 : (by ? 0.0 : 1.0);
-#pragma unroll
-      for (int ax = 0; ax < 2; ++ax) {
-        const double  wx  = oddx ? 0.5 : (ax ? 0.0 : 1.0);
-        const double  w   = wx * wy * wz;
-        const int32_t off = base + (cz & oddz) * cnxy + (by & oddy) * cnx + (ax & oddx);
-        s0                = s0 + w * *at_bytes(ec, 8u * (uint32_t)off);
-        s1                = s1 + w * *at_bytes(ec, 8u * (uint32_t)(off + second));
-      }
-    }
-  }
-  v.x = v.x + s0;
-  if (i1 < L.nx) v.y = v.y + s1;
   *reinterpret_cast<d2t *>(px) = v;
 }
 
@@ -227,73 +150,6 @@ __global__ __launch_bounds__(256) void q1_restrict_pair_kernel(pmgk_grid_layout 
   double *o = bc + I0 + (int64_t)C.nx * (Jc + (int64_t)C.ny * (K - C.kz0 + 1));
   o[0]      = s0;
   if (has1) o[1] = s1;
-}
-
-// prolongation: thread = the two same-colour fine points i0 = 4t + p, i1 = i0 + 2 (one 16-byte read-modify-write), whose
-// coarse neighbours in x are 2t, 2t+1, 2t+2: one 16-byte load per (cz, by) coarse line + the next lane's first value
-__global__ __launch_bounds__(256) void q1_prolong_add_pair_kernel(pmgk_grid_layout L, pmgk_st27_dims C, int kbegin, int tplE, int csel, const double *__restrict__ ec, double *__restrict__ x)
-{
-  const int lane = threadIdx.x; // block (64, 4)
-  const int flat = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x, j = flat / tplE, t = flat - j * tplE;
-  const int k = kbegin + (int)(csel >= 0 ? blockIdx.z : blockIdx.z >> 1), c = csel >= 0 ? csel : (int)(blockIdx.z & 1); // k: local plane, -1 / nz = ghosts
-  const bool live = j < L.ny && 2 * t < L.sx;
-  const int  jc = j < L.ny ? j : L.ny - 1;
-  const int  kg = k + L.kz0, p = (c + jc + kg) & 1;
-  const int  i0 = 4 * t + p, i1 = i0 + 2;
-  const bool act0 = live && i0 < L.nx, act1 = act0 && i1 < L.nx;
-  const int32_t cnx = C.nx, cnxy = C.nx * C.ny;
-  const int     oddx = p, oddy = jc & 1, oddz = kg & 1;
-  const int     I0 = min(2 * t, cnx - 1); // clamped for the lanes behind the line end (their values feed nobody)
-  const int32_t base = ((kg >> 1) - C.kz0 + 1) * cnxy + (jc >> 1) * cnx;
-  const bool    own_right = lane == 63 || t == tplE - 1; // the next lane is on another line: fetch coarse 2t + 2 myself
-  // the fine values first (lanes without a point read a valid slot of their line and drop it): one memory round trip
-  // for everything instead of the coarse rows and then the read-modify-write
-  double   *px = x + (int64_t)c * L.cs + (int64_t)(k + 1) * L.sp + (int64_t)jc * L.sx + 2 * min(t, tplE - 1);
-  d2t       v  = *reinterpret_cast<d2t *>(px);
-  double    A[4], B[4], Cn[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double *row = ec + base + ((r >> 1) & oddz) * cnxy + ((r & 1) & oddy) * cnx;
-    if (I0 + 1 < cnx) {
-      const d2a w = *reinterpret_cast<const d2a *>(row + I0);
-      A[r]        = w.x;
-      B[r]        = w.y;
-    } else {
-      A[r] = B[r] = row[I0];
-    }
-    Cn[r] = lane_next(A[r]); // coarse 2t + 2 = the next thread's first value
-  }
-  if (own_right) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double *row = ec + base + ((r >> 1) & oddz) * cnxy + ((r & 1) & oddy) * cnx;
-      Cn[r]             = (oddx && act1) ? row[I0 + 2] : B[r];
-    }
-  }
-  double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-  for (int cz = 0; cz < 2; ++cz) {
-    const double wz = oddz ? 0.5 : (cz ? 0.0 : 1.0);
-#pragma unroll
-    for (int by = 0; by < 2; ++by) {
-      const double wy = oddy ? 0.5 : (by ? 0.0 : 1.0);
-      const int    r  = 2 * cz + by;
-#pragma unroll
-      for (int ax = 0; ax < 2; ++ax) {
-        const double wx = oddx ? 0.5 : (ax ? 0.0 : 1.0);
-        const double w  = wx * wy * wz;
-        // point 0 reads coarse 2t + (ax & oddx); point 1 the same shifted by one when it exists (else it is not stored)
-        const double v0 = (ax & oddx) ? B[r] : A[r];
-        const double v1 = act1 ? ((ax & oddx) ? Cn[r] : B[r]) : v0;
-        s0              = s0 + w * v0;
-        s1              = s1 + w * v1;
-      }
-    }
-  }
-  if (!act0) return;
-  v.x = v.x + s0;
-  if (act1) v.y = v.y + s1;
-  *reinterpret_cast<d2t *>(px) = v;
 }
 
 // prolongation, single device: thread = the colour-c points i0, i0+2 of the FOUR fine lines (2J, 2J+1) x (2K, 2K+1), which
@@ -415,13 +271,8 @@ extern "C" int pmgk_q1_restrict(const pmgk_grid_layout *L, const pmgk_st27_dims 
   const int  rx = C->nx != L->nx, ry = C->ny != L->ny, rz = C->nzg != L->nzg;
   const dim3 block(256), grid((unsigned)(((int64_t)C->nx * C->ny + 255) / 256), 1, C->nz);
   if (transfer_full_case(L, C, cpos)) {
-    static const int pair = getenv("PMG_TRANSFER_PAIR") ? atoi(getenv("PMG_TRANSFER_PAIR")) : 1;
-    if (pair) {
-      const int tplC = (C->nx + 1) / 2;
-      hipLaunchKernelGGL(q1_restrict_pair_kernel, dim3((unsigned)(((int64_t)C->ny * tplC + 255) / 256), 1, C->nz), block, 0, (hipStream_t)stream, *L, *C, tplC, r_cvec, bc);
-    } else {
-      hipLaunchKernelGGL(q1_restrict_full_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, r_cvec, bc);
-    }
+    const int tplC = (C->nx + 1) / 2;
+    hipLaunchKernelGGL(q1_restrict_pair_kernel, dim3((unsigned)(((int64_t)C->ny * tplC + 255) / 256), 1, C->nz), block, 0, (hipStream_t)stream, *L, *C, tplC, r_cvec, bc);
     return launch_status();
   }
   hipLaunchKernelGGL(q1_restrict_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, cpos, r_cvec, bc);
@@ -435,20 +286,13 @@ extern "C" int pmgk_q1_prolong_add(const pmgk_grid_layout *L, const pmgk_st27_di
   const int  rx = C->nx != L->nx, ry = C->ny != L->ny, rz = C->nzg != L->nzg;
   const int  tplE = ((L->nx + 1) / 2 + 1) / 2;
   const dim3 block(64, 4), grid((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, only_color >= 0 ? kcount : 2 * kcount);
-  if (transfer_full_case(L, C, cpos)) {
-    static const int pair = getenv("PMG_TRANSFER_PAIR") ? atoi(getenv("PMG_TRANSFER_PAIR")) : 1;
-    static const int quad = getenv("PMG_TRANSFER_QUAD") ? atoi(getenv("PMG_TRANSFER_QUAD")) : 1;
-    if (pair && quad && C->ny == (L->ny + 1) / 2 && C->nzg == (L->nzg + 1) / 2) {
-      const int  gbeg = L->kz0 + kbegin, gend = gbeg + kcount; // global planes
-      const int  npair = (L->ny + 1) / 2, nkp = ((gend - 1) >> 1) - (gbeg >> 1) + 1;
-      const int64_t nb = ((int64_t)npair * tplE + 255) / 256;
-      const int     runs = nb >= 64; // below that the padding to a multiple of 8 costs more than the shared rows bring (257^3: 35 vs 39 us)
-      const dim3    qgrid((unsigned)(runs ? (nb + 7) / 8 * 8 : nb), 1, only_color >= 0 ? nkp : 2 * nkp);
-      hipLaunchKernelGGL(q1_prolong_add_quad_kernel, qgrid, dim3(256), 0, (hipStream_t)stream, *L, *C, tplE, only_color, runs, gbeg, gend, ec, x_cvec);
-      return launch_status();
-    }
-    if (pair) hipLaunchKernelGGL(q1_prolong_add_pair_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, kbegin, tplE, only_color, ec, x_cvec);
-    else hipLaunchKernelGGL(q1_prolong_add_full_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, kbegin, tplE, only_color, ec, x_cvec);
+  if (transfer_full_case(L, C, cpos) && C->ny == (L->ny + 1) / 2 && C->nzg == (L->nzg + 1) / 2) { // otherwise (semicoarsened, permuted or even extents): the generic kernel
+    const int  gbeg = L->kz0 + kbegin, gend = gbeg + kcount; // global planes
+    const int  npair = (L->ny + 1) / 2, nkp = ((gend - 1) >> 1) - (gbeg >> 1) + 1;
+    const int64_t nb = ((int64_t)npair * tplE + 255) / 256;
+    const int     runs = nb >= 64; // below that the padding to a multiple of 8 costs more than the shared rows bring (257^3: 35 vs 39 us)
+    const dim3    qgrid((unsigned)(runs ? (nb + 7) / 8 * 8 : nb), 1, only_color >= 0 ? nkp : 2 * nkp);
+    hipLaunchKernelGGL(q1_prolong_add_quad_kernel, qgrid, dim3(256), 0, (hipStream_t)stream, *L, *C, tplE, only_color, runs, gbeg, gend, ec, x_cvec);
     return launch_status();
   }
   hipLaunchKernelGGL(q1_prolong_add_kernel, grid, block, 0, (hipStream_t)stream, *L, *C, rx, ry, rz, kbegin, tplE, only_color, cpos, ec, x_cvec);
