@@ -91,7 +91,7 @@ __device__ __forceinline__ double table_at(const double (&a)[8], int idx)
 // dealt to the wavefronts without gaps.  With one line per wavefront (the default) a line of a 2^k+1 grid -- the
 // multigrid sizes -- needs one wavefront more than its power-of-two neighbour and leaves it almost empty (257: 65
 // threads in 128 lanes); packed, every wavefront is full.  Same arithmetic per point, so the results do not change.
-// one wavefront waits (lane 0 polls, the others follow) until *f >= v; gives up after ~10 s.  The flag words and the
+// one wavefront waits (lane 0 polls, the others follow) until *f >= v; gives up after ~90 s (2^28 polls: four ranks SHARING one GPU have been seen to keep a neighbour's kernel off the device for a minute; the shorter limit of round 1 turned that into an error).  The flag words and the
 // planes they announce live in FINE-GRAINED memory (never cached in L2), so relaxed polls and a plain ordering fence
 // are enough -- a system-scope acquire would invalidate the L2 under the interior sweep on every poll.
 __device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, unsigned *err)
@@ -102,8 +102,13 @@ __device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, un
       __builtin_amdgcn_s_sleep(8);
       ++spins;
       if ((spins & 0xFFFFu) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break; // somebody already gave up: do not stack timeouts
-      if (spins > (1ull << 25)) {
-        if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (spins > (1ull << 28)) {
+        if (err) { // what was waited for: [1] = wait site, [2] = expected, [3] = seen (low words)
+          err[1] = 0x10u;
+          err[2] = (unsigned)v;
+          err[3] = (unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         break;
       }
     }

@@ -29,7 +29,7 @@ __device__ __forceinline__ void copy_segments(const pmgk_xch_args &a)
   }
 }
 
-__global__ __launch_bounds__(256) void xch_push_kernel(pmgk_xch_args a, unsigned *counter)
+__global__ __launch_bounds__(256) void xch_push_kernel(pmgk_xch_args a, unsigned *counter, unsigned *dbg)
 {
   copy_segments<false, true>(a);
   __threadfence_system();
@@ -41,7 +41,11 @@ __global__ __launch_bounds__(256) void xch_push_kernel(pmgk_xch_args a, unsigned
       __threadfence_system();
       for (int q = 0; q < 4; ++q)
         if (a.flag[q]) __hip_atomic_store(a.flag[q], a.value[q], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+      if (dbg) { // diagnostics: number of pushes that raised their flags, and the last sequence number raised
+        dbg[0] += 1;
+        dbg[1] = (unsigned)a.value[0] | (unsigned)a.value[1] << 16;
+      }
+    } else if (dbg && done >= gridDim.x) dbg[2] = done; // the counter did not start at zero
   }
 }
 
@@ -57,7 +61,12 @@ __global__ __launch_bounds__(256) void xch_pull_kernel(pmgk_xch_args a, unsigned
         __builtin_amdgcn_s_sleep(32);
         ++spins;
         const bool gave_up = (spins & 0xFFFu) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (gave_up || spins > (1ull << 24)) {
+        if (gave_up || spins > (1ull << 26)) {
+          if (err && !gave_up) { // what was waited for: [1] = wait site, [2] = expected, [3] = seen (low words)
+            err[1] = 0x30u + (unsigned)q;
+            err[2] = (unsigned)a.value[q];
+            err[3] = (unsigned)__hip_atomic_load(a.flag[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
           if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           ok = 0;
           break;
@@ -99,7 +108,12 @@ __global__ void allgather_wait_kernel(int nranks, int me, const uint64_t *myflag
     __builtin_amdgcn_s_sleep(32);
     ++spins;
     const bool gave_up = (spins & 0xFFFu) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (gave_up || spins > (1ull << 24)) {
+    if (gave_up || spins > (1ull << 26)) {
+      if (err && !gave_up) {
+        err[1] = 0x40u + (unsigned)p;
+        err[2] = (unsigned)value;
+        err[3] = (unsigned)__hip_atomic_load(myflags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
@@ -158,14 +172,16 @@ extern "C" int pmgk_allgather_wait(int nranks, int me, const uint64_t *myflags, 
   return launch_status();
 }
 
-extern "C" int pmgk_xch_push(const pmgk_xch_args *a, unsigned *counter, void *stream)
+extern "C" int pmgk_xch_push_dbg(const pmgk_xch_args *a, unsigned *counter, unsigned *dbg, void *stream)
 {
   int64_t total = 0;
   for (int q = 0; q < a->nseg; ++q) total += a->n[q];
   const int nb = total > 0 ? (int)((total + 4095) / 4096 < 64 ? (total + 4095) / 4096 : 64) : 1;
-  hipLaunchKernelGGL(xch_push_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, counter);
+  hipLaunchKernelGGL(xch_push_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *a, counter, dbg);
   return launch_status();
 }
+
+extern "C" int pmgk_xch_push(const pmgk_xch_args *a, unsigned *counter, void *stream) { return pmgk_xch_push_dbg(a, counter, nullptr, stream); }
 
 extern "C" int pmgk_xch_pull(const pmgk_xch_args *a, unsigned *err, void *stream)
 {

@@ -85,12 +85,14 @@ typedef struct {
   hipIpcMemHandle_t mem;   /* the rank's receive block */
   int64_t           plane; /* doubles per plane (must agree between neighbours) */
   int64_t           gcap;  /* doubles per generic message slot */
+  int64_t           pooled; /* the block lives as long as its process: a peer may keep its mapping (ipc_open_cached) */
 } pmg_ipc_blob;
 
 struct pmg_dist_s {
   int           transport; /* 0 = RCCL, 1 = IPC peer stores + flag words */
   /* ipc: block = [PMG_IPC_HDR flag doubles][recv: 4 planes][grecv: 2 parities x 2 sides x gcap] */
   double       *block, *peer_block[2]; /* own / neighbours' blocks (side 0 = lo, 1 = hi) */
+  int           block_pooled, peer_cached[2], all_cached[PMG_IPC_MAXRANKS]; /* process-wide pool / table of open handles: see ipc_pool_get */
   double       *recv, *peer_recv[2];
   double       *grecv, *peer_grecv[2];
   uint64_t      round[2];              /* pushes of colour c issued so far */
@@ -181,6 +183,78 @@ pmg_status pmg_dist_create(pmg_grid g, int32_t rank, int32_t nranks, const void 
 
 /* ---- IPC transport --------------------------------------------------------------------------------------- */
 
+/* Receive blocks and the peers' mappings of them live as long as the process: a chain of objects in one process
+   (bench.py: headline sampler, then three V-cycle lines) would otherwise free, allocate, export and re-open a block of
+   the same size four times per rank, and freeing a block that a peer had mapped a moment ago has failed on this runtime
+   before (pmg_dist_ipc_disconnect).  A block goes back to a pool and is handed out again -- the same handle, found in
+   the peer's table of open handles; nothing is closed, nothing is freed; a few blocks of tens of MB per process.  Blocks
+   beyond the pool are ordinary allocations, and peers do not keep their mappings (the blob says which kind it is).
+   Not thread-safe, like the rest of the object's life cycle. */
+#define PMG_IPC_POOL 16
+#define PMG_IPC_MAPS 128
+static struct {
+  double *ptr;
+  size_t  bytes;
+  int     busy;
+} g_ipc_pool[PMG_IPC_POOL];
+static struct {
+  hipIpcMemHandle_t h;
+  void             *ptr;
+} g_ipc_maps[PMG_IPC_MAPS];
+static int g_ipc_nmaps;
+
+static double *ipc_pool_get(size_t bytes, int *pooled)
+{
+  *pooled = 1;
+  for (int q = 0; q < PMG_IPC_POOL; ++q)
+    if (g_ipc_pool[q].ptr && !g_ipc_pool[q].busy && g_ipc_pool[q].bytes == bytes) {
+      g_ipc_pool[q].busy = 1;
+      return g_ipc_pool[q].ptr;
+    }
+  double *p = NULL;
+  if (hipExtMallocWithFlags((void **)&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) return NULL;
+  for (int q = 0; q < PMG_IPC_POOL; ++q)
+    if (!g_ipc_pool[q].ptr) {
+      g_ipc_pool[q].ptr   = p;
+      g_ipc_pool[q].bytes = bytes;
+      g_ipc_pool[q].busy  = 1;
+      return p;
+    }
+  *pooled = 0; /* pool full: an ordinary allocation, freed with the object */
+  return p;
+}
+
+static void ipc_pool_put(double *p, int pooled)
+{
+  if (!p) return;
+  if (!pooled) {
+    (void)hipFree(p);
+    return;
+  }
+  for (int q = 0; q < PMG_IPC_POOL; ++q)
+    if (g_ipc_pool[q].ptr == p) g_ipc_pool[q].busy = 0;
+}
+
+/* the mapping of a peer's block: opened once per handle and kept */
+static hipError_t ipc_open_cached(void **ptr, hipIpcMemHandle_t h, int pooled, int *cached)
+{
+  for (int q = 0; q < g_ipc_nmaps && pooled; ++q)
+    if (!memcmp(&g_ipc_maps[q].h, &h, sizeof h)) {
+      *ptr    = g_ipc_maps[q].ptr;
+      *cached = 1;
+      return hipSuccess;
+    }
+  const hipError_t e = hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+  *cached            = 0;
+  if (e == hipSuccess && pooled && g_ipc_nmaps < PMG_IPC_MAPS) { /* a block that its owner may free is never kept: its handle could come back for other memory */
+    g_ipc_maps[g_ipc_nmaps].h   = h;
+    g_ipc_maps[g_ipc_nmaps].ptr = *ptr;
+    ++g_ipc_nmaps;
+    *cached = 1;
+  }
+  return e;
+}
+
 pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dist *out)
 {
   PMG_CHECK(out, PMG_ERR_ARG_NULL, "null argument"); /* g == NULL: a transport without a slab */
@@ -204,7 +278,12 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
   /* fine-grained device memory: flag words and planes are written by a PEER device while this device's kernels poll
      and read them IN THE SAME KERNEL, so the block must be coherent at system scope without cache maintenance (what
      RCCL uses for its peer-written buffers) */
-  if (!st && hipExtMallocWithFlags((void **)&d->block, bytes, hipDeviceMallocFinegrained) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipExtMallocWithFlags(fine-grained) of the halo receive block failed");
+  if (!st && !(d->block = ipc_pool_get(bytes, &d->block_pooled))) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipExtMallocWithFlags(fine-grained) of the halo receive block failed");
+  /* the flag words are sequence numbers that only grow: a block handed out again after an earlier object of this
+     process still holds that object's (large) numbers, and every wait of the new object would pass before its data has
+     arrived -- or a neighbour's small number would replace a large one under a waiting wavefront.  Zero the block before
+     anybody can have its handle (export comes later, behind the launcher's barrier). */
+  if (!st && (hipMemset(d->block, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "clearing the halo receive block failed");
   d->recv  = d->block ? d->block + PMG_IPC_HDR : NULL;
   d->grecv = d->block ? d->recv + 4 * d->plane : NULL;
   if (!st && hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "stream creation failed");
@@ -214,8 +293,8 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
   if (!st && hipEventCreateWithFlags(&d->evS, hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
   for (int q = 0; q < PMG_IPC_WINDOW && !st; ++q)
     if (hipEventCreateWithFlags(&d->evT[q], hipEventDisableTiming) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "event creation failed");
-  if (!st && hipHostMalloc((void **)&d->err_dev, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipHostMalloc failed");
-  if (!st) *d->err_dev = 0;
+  if (!st && hipHostMalloc((void **)&d->err_dev, 8 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "hipHostMalloc failed");
+  if (!st) memset(d->err_dev, 0, 8 * sizeof(unsigned));
   if (!st) st = pmg_dev_alloc((void **)&d->xch_counter, 2 * sizeof(unsigned)); /* [0] generic exchange, [1] face wavefronts */
   if (!st && hipMemset(d->xch_counter, 0, 2 * sizeof(unsigned)) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
   if (st) {
@@ -239,8 +318,9 @@ pmg_status pmg_dist_ipc_export(pmg_dist d, void *blob)
   pmg_ipc_blob bl;
   memset(&bl, 0, sizeof bl);
   PMG_HIP(hipIpcGetMemHandle(&bl.mem, d->block));
-  bl.plane = d->plane;
-  bl.gcap  = d->gcap;
+  bl.plane  = d->plane;
+  bl.gcap   = d->gcap;
+  bl.pooled = d->block_pooled;
   memcpy(blob, &bl, sizeof bl);
   return PMG_SUCCESS;
 }
@@ -257,7 +337,7 @@ pmg_status pmg_dist_ipc_connect(pmg_dist d, const void *blob_lo, const void *blo
     pmg_ipc_blob bl;
     memcpy(&bl, blobs[side], sizeof bl);
     PMG_CHECK(bl.plane == d->plane && bl.gcap == d->gcap, PMG_ERR_ARG_SIZ, "neighbour receive block (%lld, %lld) != (%lld, %lld)", (long long)bl.plane, (long long)bl.gcap, (long long)d->plane, (long long)d->gcap);
-    PMG_HIP(hipIpcOpenMemHandle((void **)&d->peer_block[side], bl.mem, hipIpcMemLazyEnablePeerAccess));
+    PMG_HIP(ipc_open_cached((void **)&d->peer_block[side], bl.mem, bl.pooled != 0, &d->peer_cached[side]));
     d->peer_recv[side]  = d->peer_block[side] + PMG_IPC_HDR;
     d->peer_grecv[side] = d->peer_recv[side] + 4 * d->plane;
   }
@@ -283,7 +363,7 @@ pmg_status pmg_dist_ipc_connect_all(pmg_dist d, const void *const *blobs)
       pmg_ipc_blob bl;
       memcpy(&bl, blobs[r], sizeof bl);
       PMG_CHECK(bl.plane == d->plane && bl.gcap == d->gcap, PMG_ERR_ARG_SIZ, "rank %d has a different receive block", r);
-      PMG_HIP(hipIpcOpenMemHandle((void **)&d->all_block[r], bl.mem, hipIpcMemLazyEnablePeerAccess));
+      PMG_HIP(ipc_open_cached((void **)&d->all_block[r], bl.mem, bl.pooled != 0, &d->all_cached[r]));
     }
     double *gather = d->all_block[r] + PMG_IPC_HDR + 4 * d->plane + 4 * d->gcap;
     dst[0][r]      = gather;
@@ -331,7 +411,13 @@ static uint64_t *flag_peer(pmg_dist d, int side, int idx) { return (side == 0 ? 
 /* a flag wait of an EARLIER round gave up (lost neighbour): fail the next call instead of computing on */
 static pmg_status ipc_check(pmg_dist d)
 {
-  PMG_CHECK(*(volatile unsigned *)d->err_dev == 0, PMG_ERR_LIB, "rank %d: a halo flag never arrived (neighbour lost?)", d->rank);
+  volatile unsigned *e = (volatile unsigned *)d->err_dev;
+  if (e[0] != 0 && getenv("PMG_IPC_DEBUG")) { /* my flag words as they are now: [0..3] colour planes, [4..5] generic, [8+r] all-gather */
+    uint64_t w[16];
+    if (hipMemcpy(w, d->block, sizeof w, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[pmg ipc debug] rank %d block %p flags: planes %llu %llu %llu %llu generic %llu %llu gather %llu %llu %llu %llu; rounds %llu %llu ground %llu\n", d->rank, (void *)d->block, (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3], (unsigned long long)w[4], (unsigned long long)w[5], (unsigned long long)w[8], (unsigned long long)w[9], (unsigned long long)w[10], (unsigned long long)w[11], (unsigned long long)d->round[0], (unsigned long long)d->round[1], (unsigned long long)d->ground);
+  } /* [1..3]: wait site (0x10 face plane, 0x30+q generic message, 0x40+r all-gather block of rank r), sequence number expected / seen; all 0 if another wait of this rank gave up first */
+  PMG_CHECK(e[0] == 0, PMG_ERR_LIB, "rank %d: a halo flag never arrived (neighbour lost?): wait site 0x%x, expected %u, seen %u, exchanges %llu, all-gathers %llu; my pushes that raised flags %u (last numbers 0x%x), counter fault %u", d->rank, e[1], e[2], e[3], (unsigned long long)d->ground, (unsigned long long)d->aground, e[4], e[5], e[6]);
   return PMG_SUCCESS;
 }
 
@@ -361,7 +447,7 @@ static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its
         push.value[c * 2 + side] = d->round[c];
       }
     }
-    PMG_KERNEL(pmgk_xch_push(&push, d->xch_counter, s));
+    PMG_KERNEL(pmgk_xch_push_dbg(&push, d->xch_counter, d->err_dev + 4, s));
   }
   uint64_t ctr = counter0;
   for (int32_t it = 0; it < its; ++it) {
@@ -421,12 +507,12 @@ pmg_status pmg_dist_ipc_disconnect(pmg_dist d)
   if (d->transport != 1) return PMG_SUCCESS;
   (void)hipDeviceSynchronize();
   for (int r = 0; r < d->nranks && d->all_connected; ++r) {
-    if (d->all_block[r] && r != d->lo && r != d->hi && r != d->rank) (void)hipIpcCloseMemHandle(d->all_block[r]);
+    if (d->all_block[r] && r != d->lo && r != d->hi && r != d->rank && !d->all_cached[r]) (void)hipIpcCloseMemHandle(d->all_block[r]);
     d->all_block[r] = NULL;
   }
   d->all_connected = 0;
   for (int side = 0; side < 2 && !d->loopback; ++side) {
-    if (d->peer_block[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
+    if (d->peer_block[side] && !d->peer_cached[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
     d->peer_block[side] = NULL;
     d->peer_recv[side] = d->peer_grecv[side] = NULL;
   }
@@ -440,17 +526,17 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
   if (d->transport == 1) {
     (void)hipDeviceSynchronize();
     for (int side = 0; side < 2 && !d->loopback; ++side)
-      if (d->peer_block[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
+      if (d->peer_block[side] && !d->peer_cached[side]) (void)hipIpcCloseMemHandle(d->peer_block[side]);
     for (int q = 0; q < PMG_IPC_WINDOW; ++q)
       if (d->evT[q]) (void)hipEventDestroy(d->evT[q]);
     for (int r = 0; r < d->nranks && d->all_connected; ++r)
-      if (d->all_block[r] && r != d->lo && r != d->hi && r != d->rank) (void)hipIpcCloseMemHandle(d->all_block[r]);
+      if (d->all_block[r] && r != d->lo && r != d->hi && r != d->rank && !d->all_cached[r]) (void)hipIpcCloseMemHandle(d->all_block[r]);
     pmg_dev_free(d->ag_dst_dev[0]);
     pmg_dev_free(d->ag_dst_dev[1]);
     pmg_dev_free(d->ag_flag_dev);
     if (d->err_dev) (void)hipHostFree(d->err_dev);
     pmg_dev_free(d->xch_counter);
-    if (d->block) (void)hipFree(d->block);
+    ipc_pool_put(d->block, d->block_pooled);
   }
   pmg_dev_free(d->red_buf);
   if (d->comm && d->api.CommDestroy) d->api.CommDestroy(d->comm);
@@ -533,7 +619,7 @@ pmg_status pmg_dist_exchange(pmg_dist d, int nseg, const double *const *send_lo,
     pull.flag[side]  = flag_mine(d, 4 + side);
     push.value[side] = pull.value[side] = d->ground;
   }
-  PMG_KERNEL(pmgk_xch_push(&push, d->xch_counter, s));
+  PMG_KERNEL(pmgk_xch_push_dbg(&push, d->xch_counter, d->err_dev + 4, s));
   PMG_KERNEL(pmgk_xch_pull(&pull, d->err_dev, s));
   return ipc_throttle(d, s);
 }

@@ -160,6 +160,7 @@ typedef struct {
   uint64_t      value[4];
 } pmgk_xch_args;
 int pmgk_xch_push(const pmgk_xch_args *a, unsigned *counter, void *stream);
+int pmgk_xch_push_dbg(const pmgk_xch_args *a, unsigned *counter, unsigned *dbg, void *stream); /* dbg[0..2]: pushes that raised their flags, last sequence numbers, a counter that did not start at zero */
 /* all-gather over all-peer mappings: push = copy my block (n doubles at src) to dst[p] + dst_off for every peer
    p != me (device array of nranks pointers; null = skip), then raise flag[p] (device array) to value from the last
    block; wait = until myflags[p] >= value for every p != me */

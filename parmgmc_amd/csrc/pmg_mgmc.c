@@ -612,6 +612,7 @@ static int st27_use_pair_slab(const mg_level *Lv)
   }
   return env && Lv->is_st27 && Lv->distributed;
 }
+static int st27_pair_slab_mode(void) { const char *e = getenv("PMG_ST27_PAIR_SLAB"); return e ? atoi(e) : 1; } /* probe: 2 = residual only, 3 = sweeps only */
 
 /* one directional sweep of a class-stencil level on (b, *x): in place, or out of place into Lv->x2 followed by a swap of
    the two buffers when x is the level's own iterate */
@@ -1393,7 +1394,7 @@ static pmg_status st27_sample(pmg_mgmc h, mg_level *Lv, int its, uint64_t seed, 
       const int     backward = ndir == 2 ? d : h->sweep_type == PMG_SOR_BACKWARD_SWEEP;
       const double *rhs      = Lv->b;
       if (Lv->lrc) PMG_CALL(pmg_lrc_rhs(Lv->lrc, Lv->b, seed, *ctr, &rhs, stream)); /* + B (sqrt(S) o eta), src/pc_mcgibbs.c:130-140 */
-      if (Lv->distributed && Lv->x2 && st27_use_pair_slab(Lv)) { /* out of place: x2 <- sweep(x), phase by phase, then the buffers swap */
+      if (Lv->distributed && Lv->x2 && st27_use_pair_slab(Lv) && st27_pair_slab_mode() != 2) { /* out of place: x2 <- sweep(x), phase by phase, then the buffers swap */
         PMG_KERNEL(pmgk_st27_sweep_pp_phase(&S, backward, 0, h->omega, 1, seed, *ctr, rhs, Lv->x, Lv->x2, stream));
         PMG_CALL(halo_level(h, Lv, Lv->x2, stream));
         PMG_KERNEL(pmgk_st27_sweep_pp_phase(&S, backward, 1, h->omega, 1, seed, (*ctr)++, rhs, Lv->x, Lv->x2, stream));
@@ -1534,7 +1535,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     }
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
     else if (Lv->is_st27) {
-      if (st27_use_pair(Lv) || st27_use_pair_slab(Lv)) PMG_KERNEL(pmgk_st27_residual_pair(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
+      if (st27_use_pair(Lv) || (st27_use_pair_slab(Lv) && st27_pair_slab_mode() != 3)) PMG_KERNEL(pmgk_st27_residual_pair(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
       else PMG_KERNEL(pmgk_st27_residual(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
       if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* PCMGSetResidual(..., As[l]), src/pc_gamgmc.c:194 */
     }

@@ -246,7 +246,7 @@ class IpcSlabDriver(RcclSlabDriver):
     def _selftest(self, rank, world):
         """One round trip of a known pattern with both z-neighbours (peer copies into their blocks, flag words, copy
         out): if peer access or the flags do not work on this machine the constructor fails -- on every rank, the
-        wait gives up after ~10 s -- and DistGridSampler moves on to the next transport."""
+        wait gives up after about a minute -- and DistGridSampler moves on to the next transport."""
         import ctypes as C
 
         import torch
