@@ -276,6 +276,16 @@ pmg_status pmg_distmcsor_create(pmg_mcsor mc, pmg_dist dist, int32_t ncolors, co
    work between colours.  Collective.  Bit-identical to the single-process chain for any number of ranks. */
 pmg_status pmg_distmcsor_sample_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
 pmg_status pmg_distmcsor_apply_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int sweep_type, void *stream);
+/* MATLRC operator A + B S B^T on row blocks (src/mc_sor.c:572-595 on a MATMPIAIJ base): B_local is nlocal x k column-major
+   in the local row numbering (nlocal = rows of the local operator; this rank's `nowned` rows first; ghost entries ignored), S the k diagonal entries of
+   Sigma^-1.  Afterwards every directional sweep of pmg_distmcsor_sample_layout / _apply_layout is followed by
+   y -= Bb (B^T y) (:101-112; B^T y is all-reduced in rank order) and every noisy right-hand side gets
+   + B (sqrt(S) o eta).  Collective (the correction is built with distributed sweeps); k = 0 removes the update.
+   _dev: B already in the operator's layout on the device (ld x k), zero on the ghost rows.
+   pmg_distmcsor_residual_layout: r = b - (A + B S B^T) y on the owned rows. */
+pmg_status pmg_distmcsor_set_lowrank(pmg_distmcsor h, int32_t k, int32_t nlocal, int32_t nowned, const double *B_local_host, const double *S_host);
+pmg_status pmg_distmcsor_set_lowrank_dev(pmg_distmcsor h, int32_t k, const double *B_layout_dev, const double *S_host);
+pmg_status pmg_distmcsor_residual_layout(pmg_distmcsor h, const double *b_lay, const double *y_lay, double *r_lay, void *stream);
 /* refresh every ghost row of a layout vector from its owner (collective) */
 pmg_status pmg_distmcsor_refresh_layout(pmg_distmcsor h, double *v_lay, void *stream);
 pmg_status pmg_distmcsor_destroy(pmg_distmcsor *h);

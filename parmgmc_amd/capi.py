@@ -170,6 +170,9 @@ _sig = {
     "pmg_mgmc_set_rowblock_transport": (_int, [_vp, _vp, _vp]),
     "pmg_mgmc_set_level_rowblock": (_int, [_vp, _i32, C.c_int64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmg_mgmc_set_level_restriction": (_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "pmg_distmcsor_set_lowrank": (_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "pmg_distmcsor_set_lowrank_dev": (_int, [_vp, _i32, _vp, _vp]),
+    "pmg_distmcsor_residual_layout": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "pmg_distmcsor_refresh_layout": (_int, [_vp, _vp, _vp]),
     "pmg_mgmc_level_residual_restrict": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "pmg_mgmc_level_prolong_add": (_int, [_vp, _i32, _vp, _vp, _vp]),

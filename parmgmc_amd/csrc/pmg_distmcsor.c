@@ -36,12 +36,14 @@ struct pmg_distmcsor_s {
      all_tot = -1: the combined block exceeds the transport's capacity, refresh colour by colour */
   int64_t *all_off, *all_cnt, all_tot;
   int32_t *all_src_dev;
+  pmg_lrc  lrc; /* MATLRC update A + B S B^T of the distributed operator (pmg_distmcsor_set_lowrank) */
 };
 
 pmg_status pmg_distmcsor_destroy(pmg_distmcsor *hp)
 {
   if (!hp || !*hp) return PMG_SUCCESS;
   pmg_distmcsor h = *hp;
+  pmg_lrc_destroy(&h->lrc);
   free(h->send_ptr);
   free(h->recv_ptr);
   free(h->goff);
@@ -191,26 +193,100 @@ static pmg_status distmcsor_refresh(pmg_distmcsor h, double *y, void *stream)
   return PMG_SUCCESS;
 }
 
-static pmg_status distmcsor_sweeps(pmg_distmcsor h, const double *b, double *y, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+/* with_lrc = 0: the sweeps of A alone (what MCSORBuildLRCCorrection applies to the columns of B) */
+static pmg_status distmcsor_sweeps_x(pmg_distmcsor h, const double *b, double *y, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, int with_lrc, void *stream)
 {
   PMG_CHECK(h && b && y, PMG_ERR_ARG_NULL, "null argument");
   PMG_CHECK(its >= 0, PMG_ERR_ARG_OUTOFRANGE, "its = %d", its);
   PMG_CHECK(pmg_sweep_type_ok(sweep_type), PMG_ERR_SUP, "Only forward, backward and symmetric sweep supported");
+  pmg_lrc lrc = with_lrc ? h->lrc : NULL;
   PMG_CALL(distmcsor_refresh(h, y, stream)); /* the caller's y has no ghost values yet */
   uint64_t ctr = counter0;
   for (int32_t it = 0; it < its; ++it) {
     const int ndir = sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
     for (int q = 0; q < ndir; ++q) {
-      const int dir = ndir == 2 ? (q == 0 ? PMG_SOR_FORWARD_SWEEP : PMG_SOR_BACKWARD_SWEEP) : sweep_type;
+      const int     dir = ndir == 2 ? (q == 0 ? PMG_SOR_FORWARD_SWEEP : PMG_SOR_BACKWARD_SWEEP) : sweep_type;
+      const double *rhs = b;
+      if (lrc && noisy) PMG_CALL(pmg_lrc_rhs(lrc, b, seed, ctr, &rhs, stream)); /* + B (sqrt(S) o eta), src/pc_mcgibbs.c:130-140: eta is keyed on (seed, counter), the same on every rank */
       for (int32_t cc = 0; cc < h->ncolors; ++cc) {
         const int32_t c = dir == PMG_SOR_FORWARD_SWEEP ? cc : h->ncolors - 1 - cc; /* src/mc_sor.c:317, :344 */
-        PMG_CALL(pmg_mcsor_sweep_color_layout(h->mc, c, noisy, scaled, seed, ctr, b, y, stream));
+        PMG_CALL(pmg_mcsor_sweep_color_layout(h->mc, c, noisy, scaled, seed, ctr, rhs, y, stream));
         PMG_CALL(distmcsor_update(h, c, y, stream));
       }
+      if (lrc && noisy) PMG_CALL(pmg_lrc_rhs_done(lrc, stream));
+      /* y -= Bb (B^T y), src/mc_sor.c:101-112: B has zeros on the ghost rows (every row counts once in the all-reduced
+         k-vector), Bb carries the owners' values there, so the ghost rows receive their owners' update without an exchange */
+      if (lrc) PMG_CALL(pmg_lrc_post(lrc, dir, y, stream));
       ++ctr; /* a symmetric sweep draws twice per sample, src/pc_mcgibbs.c:172-181 */
     }
   }
   if (counter_out) *counter_out = ctr;
+  return PMG_SUCCESS;
+}
+
+static pmg_status distmcsor_sweeps(pmg_distmcsor h, const double *b, double *y, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+{
+  return distmcsor_sweeps_x(h, b, y, its, noisy, scaled, sweep_type, seed, counter0, counter_out, 1, stream);
+}
+
+static pmg_status distmcsor_det_sweep(void *ctx, int dir, const double *b, double *y, void *stream)
+{
+  return distmcsor_sweeps_x((pmg_distmcsor)ctx, b, y, 1, 0, 0, dir, 0, 0, NULL, 0, stream);
+}
+static pmg_status distmcsor_reduce(void *ctx, double *vals_dev, int count, void *stream)
+{
+  return pmg_dist_allreduce_sum(((pmg_distmcsor)ctx)->dist, vals_dev, count, stream);
+}
+
+/* MATLRC operator A + B S B^T on row blocks (MCSORSetUp's LRC branch, src/mc_sor.c:572-595, on a MATMPIAIJ base): B_lay_dev
+   is ld x k column-major in the LAYOUT of the local operator on the device, this rank's rows filled and ZERO on the ghost
+   rows; S the k diagonal entries.  The correction Bb = C (S^-1 + B^T C)^-1, C = M^-1 B (:480-544) is built with distributed
+   deterministic sweeps and rank-ordered all-reduces of the k x k products.  Collective.  k = 0 removes the update. */
+pmg_status pmg_distmcsor_set_lowrank_dev(pmg_distmcsor h, int32_t k, const double *B_lay_dev, const double *S_host)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  pmg_lrc_destroy(&h->lrc);
+  if (k == 0) return PMG_SUCCESS;
+  PMG_CHECK(B_lay_dev && S_host, PMG_ERR_ARG_NULL, "null low-rank factor");
+  PMG_CHECK(k > 0 && k <= 64, PMG_ERR_ARG_OUTOFRANGE, "rank k = %d (1..64 supported)", k);
+  int32_t ld = 0;
+  PMG_CALL(pmg_mcsor_layout_len(h->mc, &ld));
+  return pmg_lrc_build_dev(&h->lrc, k, ld, B_lay_dev, S_host, distmcsor_det_sweep, h, h->nranks > 1 ? distmcsor_reduce : NULL, h);
+}
+
+/* the same from the host: B_local is nlocal x k column-major in the local row numbering (nlocal = rows of the local
+   operator, owned rows first; the ghost rows' entries are ignored) */
+pmg_status pmg_distmcsor_set_lowrank(pmg_distmcsor h, int32_t k, int32_t nlocal, int32_t nowned, const double *B_local_host, const double *S_host)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  if (k == 0) return pmg_distmcsor_set_lowrank_dev(h, 0, NULL, NULL);
+  PMG_CHECK(B_local_host && S_host && k > 0 && k <= 64, PMG_ERR_ARG_WRONG, "low-rank factor: k = %d", k);
+  int32_t       ld = 0;
+  const int32_t n  = nlocal; /* rows of the local operator (owned + ghost), the leading dimension of B_local */
+  PMG_CALL(pmg_mcsor_layout_len(h->mc, &ld));
+  PMG_CHECK(nowned >= 0 && nowned <= n && n <= ld, PMG_ERR_ARG_OUTOFRANGE, "%d owned rows of %d local rows (layout %d)", nowned, n, ld);
+  int32_t *pos = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  double  *Bl  = (double *)calloc((size_t)ld * (size_t)k, sizeof(double));
+  pmg_status st = (pos && Bl) ? pmg_mcsor_get_layout(h->mc, pos) : pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+  double *Bd = NULL;
+  if (!st) {
+    for (int32_t c = 0; c < k; ++c)
+      for (int32_t r = 0; r < nowned; ++r) Bl[(size_t)ld * c + pos[r]] = B_local_host[(size_t)n * c + r];
+    st = pmg_dev_upload((void **)&Bd, Bl, sizeof(double) * (size_t)ld * (size_t)k);
+  }
+  free(pos);
+  free(Bl);
+  if (!st) st = pmg_distmcsor_set_lowrank_dev(h, k, Bd, S_host);
+  pmg_dev_free(Bd);
+  return st;
+}
+
+/* r = b - (A + B S B^T) y on the owned rows of layout vectors whose ghost rows are current */
+pmg_status pmg_distmcsor_residual_layout(pmg_distmcsor h, const double *b_lay, const double *y_lay, double *r_lay, void *stream)
+{
+  PMG_CHECK(h && b_lay && y_lay && r_lay, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CALL(pmg_mcsor_residual_layout(h->mc, b_lay, y_lay, r_lay, stream));
+  if (h->lrc) PMG_CALL(pmg_lrc_residual_sub(h->lrc, y_lay, r_lay, stream));
   return PMG_SUCCESS;
 }
 

@@ -509,6 +509,23 @@ class DistMCSOR:
             self._c = C.c_void_p()
             check(lib.pmg_distmcsor_create(self.mc._h, self._drv._h, ncolors, send_ptr.ctypes.data, send_pos.ctypes.data, np.ascontiguousarray(counts).ctypes.data, recv_ptr.ctypes.data, recv_src.ctypes.data, recv_pos.ctypes.data, C.byref(self._c)))
 
+    def set_lowrank(self, B_owned, S):
+        """MATLRC operator A + B diag(S) B^T (reference MCSORSetUp's LRC branch, src/mc_sor.c:572-595): B_owned = this
+        rank's rows of B (nloc x k).  C driver only (transport "ipc" / "rccl"); collective."""
+        import numpy as np
+
+        from .capi import check, lib
+
+        if self._c is None:
+            raise RuntimeError("the low-rank update of the row-block sampler needs the C driver (transport 'ipc' or 'rccl')")
+        B = np.asarray(B_owned, np.float64)
+        S = np.ascontiguousarray(S, np.float64)
+        assert B.shape == (self.nloc, len(S))
+        nl = self.nloc + len(self.ghosts)
+        Bl = np.zeros((nl, len(S)), order="F")
+        Bl[: self.nloc] = B
+        check(lib.pmg_distmcsor_set_lowrank(self._c, len(S), nl, self.nloc, Bl.ctypes.data, S.ctypes.data))
+
     def new_layout(self):
         import torch
 

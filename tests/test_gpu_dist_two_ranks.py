@@ -213,7 +213,17 @@ def test_distributed_vcycle_reproduces_the_single_device_chain(grid, levels, wor
     assert np.array_equal(np.concatenate([x[1] for x in parts]), yd.cpu().numpy())
 
 
-def _csr_worker(rank, world, port, which, omega, sweep_type, its, q, transport=None):
+def _csr_lowrank_factors(n):
+    """three observation-like vectors with supports that straddle every row-block cut, and their precisions"""
+    rng = np.random.default_rng(11)
+    B = np.zeros((n, 3))
+    for c, (lo, hi) in enumerate([(0.05, 0.45), (0.3, 0.8), (0.55, 0.98)]):
+        rows = np.arange(int(lo * n), int(hi * n), 3)
+        B[rows, c] = rng.uniform(0.5, 1.5, len(rows)) / len(rows)
+    return B, np.array([30.0, 80.0, 50.0])
+
+
+def _csr_worker(rank, world, port, which, omega, sweep_type, its, q, transport=None, lowrank=False):
     import torch
     import torch.distributed as dist
 
@@ -233,6 +243,9 @@ def _csr_worker(rank, world, port, which, omega, sweep_type, its, q, transport=N
     sl = slice(A.rowptr[r0], A.rowptr[r1])
     smp = DistMCSOR(rp, A.colidx[sl], A.vals[sl], r0, r1, n, colors[r0:r1], int(colors.max()) + 1, rank, world, omega=omega, sweep_type=sweep_type, transport=transport)
     assert smp.transport == (transport or "torch") and (smp._c is not None) == (transport == "ipc")
+    if lowrank:
+        B, S = _csr_lowrank_factors(n)
+        smp.set_lowrank(B[r0:r1], S)
     rng = np.random.default_rng(5)
     b_all, y_all = rng.standard_normal(n), rng.standard_normal(n)
     b = smp.to_layout(torch.as_tensor(b_all[r0:r1], device="cuda"))
@@ -381,3 +394,45 @@ def test_row_block_distributed_aij_vcycle_reproduces_the_single_device_chain(ref
     assert all(x[2] == ctr for x in parts)
     got = np.concatenate([x[1] for x in parts])
     assert np.isfinite(got).all() and np.array_equal(got, yd.cpu().numpy())
+
+
+@pytest.mark.parametrize("world,sweep_type", [(2, 1), (3, 3), (4, 2)], ids=["2ranks", "3ranks_symmetric", "4ranks_backward"])
+def test_row_block_sampler_with_a_low_rank_update(world, sweep_type):
+    """MATLRC operator A + B S B^T on a row-block distributed MATAIJ base (MCSORSetUp's LRC branch, reference
+    src/mc_sor.c:572-595; per-sweep repair :101-112, noise term src/pc_mcgibbs.c:130-140): the correction is built with
+    distributed deterministic sweeps and rank-ordered all-reduces, the k-vectors B^T y are summed per rank and then over
+    the ranks -- equal to the single-device sampler to rounding (1e-12), not bit for bit."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from parmgmc_amd import MCSOR
+
+    omega, its = 1.1, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_csr_worker, args=(r, world, port, "lshape", omega, sweep_type, its, q, "ipc", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = sorted((q.get(timeout=150) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    A, colors = _csr_problem("lshape")
+    rng = np.random.default_rng(5)
+    b_all, y_all = rng.standard_normal(A.n), rng.standard_normal(A.n)
+    one = MCSOR(A.rowptr, A.colidx, A.vals, user_colors=colors).setup()
+    one.set_omega(omega)
+    one.set_sweep_type(sweep_type)
+    one.set_lowrank(*_csr_lowrank_factors(A.n))
+    yd = torch.as_tensor(y_all, device="cuda")
+    ctr = one.sample(torch.as_tensor(b_all, device="cuda"), yd, its, seed=42, counter0=1)
+    assert all(x[2] == ctr for x in parts)
+    got, ref = np.concatenate([x[1] for x in parts]), yd.cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got - ref).max() / np.abs(ref).max() < 1e-12
+    plain = MCSOR(A.rowptr, A.colidx, A.vals, user_colors=colors).setup()  # the update is not a no-op
+    plain.set_omega(omega)
+    plain.set_sweep_type(sweep_type)
+    yp = torch.as_tensor(y_all, device="cuda")
+    plain.sample(torch.as_tensor(b_all, device="cuda"), yp, its, seed=42, counter0=1)
+    assert np.abs(yp.cpu().numpy() - ref).max() / np.abs(ref).max() > 1e-6
