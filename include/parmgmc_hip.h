@@ -334,7 +334,10 @@ pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc mg, int32_t level, int32_t 
    level l-1 (global for l-1 = 0) and pmg_mgmc_set_level_restriction(l) the rows of P_l^T this rank owns on level l-1,
    columns in the local numbering of level l, entries by ascending global fine row.  pmg_mgmc_sample's vectors have one
    entry per local row of the finest level (ghost entries ignored / undefined).  Same bits as the single-device chain of
-   pmg_mgmc_create_hierarchy with the same colouring.  PMG_ERR_SUP: low-rank updates, Gibbs coarse solver. */
+   pmg_mgmc_create_hierarchy with the same colouring.  pmg_mgmc_set_lowrank takes this rank's rows of B (n_local x k, ghost
+   entries ignored): the update is restricted level by level with the hierarchy's own P^T and lives in the levels' row-block
+   samplers (equal to the single-device chain to rounding: B^T y is summed per rank, then over the ranks).  PMG_ERR_SUP: Gibbs
+   coarse solver. */
 pmg_status pmg_mgmc_set_rowblock_transport(pmg_mgmc mg, pmg_dist dist, const int64_t *coarse_starts);
 pmg_status pmg_mgmc_set_level_rowblock(pmg_mgmc mg, int32_t level, int64_t row0, int32_t nowned, int32_t ncolors, const int32_t *colors_owned, const int64_t *send_ptr, const int32_t *send_rows, const int64_t *counts, const int64_t *recv_ptr, const int32_t *recv_src, const int32_t *recv_rows);
 pmg_status pmg_mgmc_set_level_restriction(pmg_mgmc mg, int32_t level, int32_t nrows, int32_t ncols, const int32_t *rowptr, const int32_t *colidx, const double *vals);

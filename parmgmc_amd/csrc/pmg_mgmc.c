@@ -441,7 +441,7 @@ pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc h, int32_t level, int32_t n
      indices for l-1 = 0); pmg_mgmc_set_level_restriction(l): the rows of R_l = P_l^T that this rank owns on level l-1,
      columns in the local numbering of level l, entries by ascending global fine row (the order of a transposition).
    Noise is keyed on global rows and every row keeps its global entry order: the chain is the single-device chain of
-   pmg_mgmc_create_hierarchy bit for bit.  Low-rank updates are not supported on row blocks. */
+   pmg_mgmc_create_hierarchy bit for bit; with a low-rank update (pmg_mgmc_set_lowrank: this rank's rows of B) to rounding. */
 pmg_status pmg_mgmc_set_rowblock_transport(pmg_mgmc h, pmg_dist dist, const int64_t *coarse_starts)
 {
   PMG_CHECK(h && dist && coarse_starts, PMG_ERR_ARG_NULL, "null argument");
@@ -771,7 +771,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     PMG_CHECK(Lv->A_user.rp, PMG_ERR_ARG_WRONGSTATE, "level %d has no operator", l);
     if (h->rb_dist) { /* row blocks: every level above the coarsest is one, the coarsest is replicated and sampled exactly */
       PMG_CHECK(l == 0 ? !Lv->rb : Lv->rb, PMG_ERR_ARG_WRONGSTATE, "row-block hierarchy: level %d %s", l, l == 0 ? "is the replicated coarsest level" : "has no row block (pmg_mgmc_set_level_rowblock)");
-      PMG_CHECK(h->coarse_type == 0 && !h->lrc_k, PMG_ERR_SUP, "row-block hierarchies: exact coarse sampler, no low-rank update");
+      PMG_CHECK(h->coarse_type == 0, PMG_ERR_SUP, "row-block hierarchies: exact coarse sampler");
       PMG_CHECK(l == 0 || (Lv->P_user.rp && Lv->R_user.rp && Lv->P_user.nr == Lv->rb_nowned && Lv->P_user.nc == h->lv[l - 1].n && Lv->R_user.nc == Lv->n), PMG_ERR_ARG_SIZ, "level %d: interpolation rows = owned rows, its columns and the restriction's in local numbering", l);
       PMG_CHECK(l == 0 || Lv->R_user.nr == (l == 1 ? (int32_t)(h->rb_c0_starts[h->rank + 1] - h->rb_c0_starts[h->rank]) : h->lv[l - 1].rb_nowned), PMG_ERR_ARG_SIZ, "level %d: the restriction has one row per owned row of level %d", l, l - 1);
       PMG_CHECK(l > 0 || h->rb_c0_starts[h->nranks] == Lv->n, PMG_ERR_ARG_SIZ, "the coarse row blocks cover %lld rows, the coarsest level has %d", (long long)h->rb_c0_starts[h->nranks], Lv->n);
@@ -822,13 +822,24 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     if (l == 0 && h->coarse_type == 0 && !h->lrc_k) PMG_CALL(pmg_chol_create_csr(Lv->n, Lv->A_user.rp, Lv->A_user.ci, Lv->A_user.v, &h->chol));
   }
   double *Bcur = h->lrc_B; /* level-l block of the low-rank factor, natural numbering (owned by h at the top) */
-  if (h->lrc_k) PMG_CALL(level_attach_lrc(h, &h->lv[top], Bcur));
+  double *Bdev = NULL;     /* row blocks: the level-l block in the level's LAYOUT on the device, zero on the ghost rows */
+  if (h->lrc_k && h->rb_dist) {
+    mg_level *T  = &h->lv[top];
+    double   *Bl = (double *)calloc((size_t)T->ld * (size_t)h->lrc_k, sizeof(double));
+    PMG_CHECK(Bl, PMG_ERR_MEM, "out of host memory");
+    for (int32_t c = 0; c < h->lrc_k; ++c)
+      for (int32_t r = 0; r < T->rb_nowned; ++r) Bl[(size_t)T->ld * c + pos[top][r]] = Bcur[(size_t)T->n * c + r];
+    pmg_status st = pmg_dev_upload((void **)&Bdev, Bl, sizeof(double) * (size_t)T->ld * (size_t)h->lrc_k);
+    free(Bl);
+    PMG_CALL(st);
+    PMG_CALL(pmg_distmcsor_set_lowrank_dev(T->dm, h->lrc_k, Bdev, h->lrc_S));
+  } else if (h->lrc_k) PMG_CALL(level_attach_lrc(h, &h->lv[top], Bcur));
   for (int l = top; l >= 1; --l) {
     mg_level *U = &h->lv[l];
     hcsr      R;
     memset(&R, 0, sizeof R);
     if (!U->rb) PMG_CALL(hcsr_transpose(&U->P_user, &R));
-    if (h->lrc_k) { /* B_{l-1} = P_l^T B_l, src/pc_gamgmc.c:177-178 */
+    if (h->lrc_k && !U->rb) { /* B_{l-1} = P_l^T B_l, src/pc_gamgmc.c:177-178 */
       mg_level *Cc = &h->lv[l - 1];
       double   *Bc = NULL;
       PMG_CALL(lrc_restrict_B(&R, h->lrc_k, U->n, Bcur, &Bc));
@@ -844,8 +855,38 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
       PMG_CALL(upload_transfer(&U->R_user, pos[l - 1] + (l == 1 ? h->rb_c0_starts[h->rank] : 0), pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
     else PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
     hcsr_free(&R);
+    if (h->lrc_k && U->rb) { /* row blocks: B_{l-1} = P_l^T B_l column by column on the device, with the V-cycle's own restriction */
+      mg_level *Cc = &h->lv[l - 1];
+      double   *Bc = NULL;
+      PMG_CALL(pmg_dev_alloc((void **)&Bc, sizeof(double) * (size_t)Cc->ld * (size_t)h->lrc_k));
+      PMG_HIP(hipMemset(Bc, 0, sizeof(double) * (size_t)Cc->ld * (size_t)h->lrc_k));
+      for (int32_t c = 0; c < h->lrc_k; ++c) {
+        double *bf = Bdev + (size_t)U->ld * c, *bc = Bc + (size_t)Cc->ld * c;
+        PMG_CALL(pmg_distmcsor_refresh_layout(U->dm, bf, NULL)); /* the rows of P^T read other ranks' rows of B */
+        PMG_KERNEL(pmgk_csr_spmv_rows(U->R_nrows, U->R_rowpos, U->R_rowptr, U->R_col, U->R_val, bf, bc, 0, NULL));
+        if (l == 1) { /* the replicated coarsest level takes the whole column */
+          int64_t cnts[64];
+          for (int r = 0; r < h->nranks; ++r) cnts[r] = h->rb_c0_starts[r + 1] - h->rb_c0_starts[r];
+          PMG_CALL(pmg_dist_allgather(h->rb_dist, bc, h->rb_c0_starts, cnts, NULL));
+        }
+      }
+      /* the refresh left copies on the ghost rows of the fine block: back to zeros there (B counts every row once) -- not
+         needed any more, the block is dropped */
+      pmg_dev_free(Bdev);
+      Bdev = Bc;
+      if (l - 1 >= 1) PMG_CALL(pmg_distmcsor_set_lowrank_dev(Cc->dm, h->lrc_k, Bdev, h->lrc_S));
+      else {
+        double *B0 = (double *)malloc(sizeof(double) * (size_t)Cc->n * (size_t)h->lrc_k);
+        PMG_CHECK(B0, PMG_ERR_MEM, "out of host memory");
+        pmg_status st = hipMemcpy(B0, Bdev, sizeof(double) * (size_t)Cc->n * (size_t)h->lrc_k, hipMemcpyDeviceToHost) == hipSuccess ? PMG_SUCCESS : pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
+        if (!st) st = pmg_chol_create_csr_lowrank(Cc->n, Cc->A_user.rp, Cc->A_user.ci, Cc->A_user.v, h->lrc_k, B0, h->lrc_S, &h->chol);
+        free(B0);
+        PMG_CALL(st);
+      }
+    }
   }
   if (Bcur != h->lrc_B) free(Bcur);
+  pmg_dev_free(Bdev);
   for (int l = 0; l <= top; ++l) {
     free(pos[l]);
     mg_level *Lv = &h->lv[l];
@@ -1539,6 +1580,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       else PMG_KERNEL(pmgk_st27_residual(&Lv->st, Lv->b, Lv->x, Lv->r, stream));
       if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* PCMGSetResidual(..., As[l]), src/pc_gamgmc.c:194 */
     }
+    else if (Lv->dm) PMG_CALL(pmg_distmcsor_residual_layout(Lv->dm, Lv->b, Lv->x, Lv->r, stream)); /* row block: + the all-reduced low-rank term */
     else PMG_CALL(pmg_mcsor_residual_layout(Lv->mc, Lv->b, Lv->x, Lv->r, stream));
     if (Lv->is_grid && Lv->lrc) PMG_CALL(pmg_lrc_residual_sub(Lv->lrc, Lv->x, Lv->r, stream)); /* z-slabs: the update of the fine level lives here, not in the grid object */
     PMG_CALL(mg_restrict(h, l, Lv->r, Cc->b, stream));
@@ -1606,6 +1648,7 @@ pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32
       PMG_HIP(hipMemcpyAsync(h->y_lay, F->x, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     } else { /* w = b - A y; work = MG(w); y += work, src/pc_gamgmc.c:253-256 */
       if (F->is_grid) PMG_CALL(pmg_grid_residual_cvec(F->g, h->b_lay, h->y_lay, F->b, stream));
+      else if (F->dm) PMG_CALL(pmg_distmcsor_residual_layout(F->dm, h->b_lay, h->y_lay, F->b, stream));
       else PMG_CALL(pmg_mcsor_residual_layout(F->mc, h->b_lay, h->y_lay, F->b, stream));
       if (F->is_grid && F->lrc) PMG_CALL(pmg_lrc_residual_sub(F->lrc, h->y_lay, F->b, stream)); /* z-slabs */
       PMG_CALL(mg_vcycle(h, seed, counter0 + (uint64_t)it, 0, stream));

@@ -781,6 +781,20 @@ class DistAIJMGMC:
 
         check(lib.pmg_mgmc_set_correction_form(self._h, int(literal)))
 
+    def set_lowrank(self, B_owned, S):
+        """MATLRC fine operator A + B diag(S) B^T, propagated to every level with the hierarchy's own restriction
+        (reference src/pc_gamgmc.c:157-196): B_owned = this rank's rows of B (n_owned x k).  Before setup()."""
+        import numpy as np
+
+        from .capi import check, lib
+
+        B = np.asarray(B_owned, np.float64)
+        S = np.ascontiguousarray(S, np.float64)
+        assert B.shape == (self.n_owned, len(S))
+        Bl = np.zeros((self.n_local, len(S)), order="F")
+        Bl[: self.n_owned] = B
+        check(lib.pmg_mgmc_set_lowrank(self._h, len(S), Bl.ctypes.data, S.ctypes.data))
+
     def setup(self):
         from .capi import check, lib
 

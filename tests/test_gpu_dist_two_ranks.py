@@ -334,9 +334,12 @@ def _aij_mg_worker(rank, world, port, refine, coarse_max, opts, its, q):
     mg = DistAIJMGMC(ops, ps, rank, world, transport="ipc")
     mg.set_smoother(opts["scaled"], opts["omega"], opts["sweep"], opts["nu"])
     mg.set_correction_form(opts["literal"])
-    mg.setup()
     n = len(ops[-1][0]) - 1
     r0, r1 = mg.row_range
+    if opts.get("lowrank"):
+        B, S = _csr_lowrank_factors(n)
+        mg.set_lowrank(B[r0:r1], S)
+    mg.setup()
     rng = np.random.default_rng(5)
     b_all, y_all = rng.standard_normal(n), rng.standard_normal(n)
     b = torch.as_tensor(b_all[r0:r1], device="cuda")
@@ -355,7 +358,9 @@ def _aij_mg_worker(rank, world, port, refine, coarse_max, opts, its, q):
     (2, 300, 3, {"scaled": True, "omega": 1.2, "sweep": 3, "nu": 2}),
     (3, 500, 4, {"scaled": True, "sweep": 2}),
     (2, 300, 2, {"literal": True, "scaled": True}),
-], ids=["2ranks", "3ranks_symmetric_nu2", "4ranks_backward_4levels", "2ranks_literal"])
+    (2, 300, 3, {"lowrank": True, "scaled": True, "sweep": 3}),
+    (3, 500, 2, {"lowrank": True, "literal": True, "scaled": True}),
+], ids=["2ranks", "3ranks_symmetric_nu2", "4ranks_backward_4levels", "2ranks_literal", "3ranks_lowrank", "2ranks_lowrank_literal"])
 def test_row_block_distributed_aij_vcycle_reproduces_the_single_device_chain(refine, coarse_max, world, opts):
     """PCGAMGMC on a MATMPIAIJ hierarchy (reference src/pc_gamgmc.c:157-223 over MCSORApply_MPIAIJ, src/mc_sor.c:298-381):
     the aggregation hierarchy of the P1 matrix of the reference's lshape.msh, every level above the coarsest split into
@@ -367,7 +372,7 @@ def test_row_block_distributed_aij_vcycle_reproduces_the_single_device_chain(ref
 
     from parmgmc_amd import MGMC
 
-    o = dict(scaled=False, omega=1.0, sweep=1, nu=1, literal=False)
+    o = dict(scaled=False, omega=1.0, sweep=1, nu=1, literal=False, lowrank=False)
     o.update(opts)
     its = 3
     ctx = mp.get_context("spawn")
@@ -388,12 +393,24 @@ def test_row_block_distributed_aij_vcycle_reproduces_the_single_device_chain(ref
     one = MGMC.from_hierarchy(ops, ps)
     one.set_smoother(o["scaled"], o["omega"], o["sweep"], o["nu"])
     one.set_correction_form(o["literal"])
+    if o.get("lowrank"):
+        one.set_lowrank(*_csr_lowrank_factors(n))
     one.setup()
     yd = torch.as_tensor(y_all, device="cuda")
     ctr = one.sample(torch.as_tensor(b_all, device="cuda"), yd, its, seed=42, counter0=1)
     assert all(x[2] == ctr for x in parts)
-    got = np.concatenate([x[1] for x in parts])
-    assert np.isfinite(got).all() and np.array_equal(got, yd.cpu().numpy())
+    got, ref = np.concatenate([x[1] for x in parts]), yd.cpu().numpy()
+    assert np.isfinite(got).all()
+    if o.get("lowrank"):  # the k-vectors B^T y are summed per rank, then over the ranks: equal to rounding, not bit for bit
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-12
+        plain = MGMC.from_hierarchy(ops, ps)  # ... and the update is not a no-op
+        plain.set_smoother(o["scaled"], o["omega"], o["sweep"], o["nu"])
+        plain.setup()
+        yp = torch.as_tensor(y_all, device="cuda")
+        plain.sample(torch.as_tensor(b_all, device="cuda"), yp, its, seed=42, counter0=1)
+        assert np.abs(yp.cpu().numpy() - ref).max() / np.abs(ref).max() > 1e-6
+        return
+    assert np.array_equal(got, ref)
 
 
 @pytest.mark.parametrize("world,sweep_type", [(2, 1), (3, 3), (4, 2)], ids=["2ranks", "3ranks_symmetric", "4ranks_backward"])
