@@ -1806,6 +1806,7 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
   free(h->lrc_B);
   free(h->lrc_S);
   free(h->cuts);
+  free(h->rb_c0_starts);
   free(h->lv);
   free(h);
   *hp = NULL;
