@@ -354,13 +354,14 @@ def _aij_mg_worker(rank, world, port, refine, coarse_max, opts, its, q):
 
 
 @pytest.mark.parametrize("refine,coarse_max,world,opts", [
+    (2, 300, 1, {"scaled": True}),
     (2, 300, 2, {}),
     (2, 300, 3, {"scaled": True, "omega": 1.2, "sweep": 3, "nu": 2}),
     (3, 500, 4, {"scaled": True, "sweep": 2}),
     (2, 300, 2, {"literal": True, "scaled": True}),
     (2, 300, 3, {"lowrank": True, "scaled": True, "sweep": 3}),
     (3, 500, 2, {"lowrank": True, "literal": True, "scaled": True}),
-], ids=["2ranks", "3ranks_symmetric_nu2", "4ranks_backward_4levels", "2ranks_literal", "3ranks_lowrank", "2ranks_lowrank_literal"])
+], ids=["1rank", "2ranks", "3ranks_symmetric_nu2", "4ranks_backward_4levels", "2ranks_literal", "3ranks_lowrank", "2ranks_lowrank_literal"])
 def test_row_block_distributed_aij_vcycle_reproduces_the_single_device_chain(refine, coarse_max, world, opts):
     """PCGAMGMC on a MATMPIAIJ hierarchy (reference src/pc_gamgmc.c:157-223 over MCSORApply_MPIAIJ, src/mc_sor.c:298-381):
     the aggregation hierarchy of the P1 matrix of the reference's lshape.msh, every level above the coarsest split into
