@@ -94,7 +94,10 @@ struct pmg_mgmc_s {
   int32_t   n_io; /* length of the caller's fine-level vectors (the owned planes) */
   /* row-block distributed caller-supplied hierarchy: transport (borrowed) and the row blocks of the replicated coarsest level */
   pmg_dist  rb_dist;
-  int64_t  *rb_c0_starts;
+  int64_t  *rb_c0_starts; /* row blocks of the highest REPLICATED level (rb_fold - 1): who restricts which of its rows */
+  int       rb_fold;      /* lowest row-block level; the levels below are replicated on every rank */
+  int32_t  *rb_fold_pos, *rb_fold_iota; /* device: layout position of natural row q of level rb_fold - 1, and 0, 1, 2, ... */
+  double   *rb_fold_buf;                /* device: that level's vector in natural order (the all-gather buffer) */
 };
 
 typedef struct {
@@ -761,6 +764,21 @@ static int        st27_from_csr(mg_level *Lv, const hcsr *A, double omega, pmg_s
 static pmg_status stencil_tables_from_proxy(pmg_mgmc h, st27_table *tab, int *ok);
 static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab);
 
+/* a vector of the highest replicated level of a row-block hierarchy, of which every rank has computed the rows of its block
+   (coarse row blocks rb_c0_starts): all ranks end up with all rows.  The coarsest level keeps natural order (one all-gather
+   in place); a sliced-ELL level goes through natural order: gather my block, all-gather, scatter everything. */
+static pmg_status rb_fold_allgather(pmg_mgmc h, double *v, void *stream)
+{
+  int64_t cnts[64];
+  for (int r = 0; r < h->nranks; ++r) cnts[r] = h->rb_c0_starts[r + 1] - h->rb_c0_starts[r];
+  if (!h->rb_fold_pos) return pmg_dist_allgather(h->rb_dist, v, h->rb_c0_starts, cnts, stream);
+  const int64_t s0 = h->rb_c0_starts[h->rank], n = h->rb_c0_starts[h->nranks];
+  PMG_KERNEL(pmgk_gather_idx(cnts[h->rank], h->rb_fold_pos + s0, v, h->rb_fold_buf + s0, stream));
+  PMG_CALL(pmg_dist_allgather(h->rb_dist, h->rb_fold_buf, h->rb_c0_starts, cnts, stream));
+  PMG_KERNEL(pmgk_scatter_idx(n, h->rb_fold_iota, h->rb_fold_pos, h->rb_fold_buf, v, stream));
+  return PMG_SUCCESS;
+}
+
 static pmg_status mgmc_setup_user(pmg_mgmc h)
 {
   const int top = h->nlevels - 1;
@@ -769,12 +787,20 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
   for (int l = 0; l <= top; ++l) {
     mg_level *Lv = &h->lv[l];
     PMG_CHECK(Lv->A_user.rp, PMG_ERR_ARG_WRONGSTATE, "level %d has no operator", l);
-    if (h->rb_dist) { /* row blocks: every level above the coarsest is one, the coarsest is replicated and sampled exactly */
-      PMG_CHECK(l == 0 ? !Lv->rb : Lv->rb, PMG_ERR_ARG_WRONGSTATE, "row-block hierarchy: level %d %s", l, l == 0 ? "is the replicated coarsest level" : "has no row block (pmg_mgmc_set_level_rowblock)");
+    if (h->rb_dist) { /* row blocks from level rb_fold upwards; the levels below are replicated (the coarsest sampled exactly) */
+      if (l == 0) {
+        h->rb_fold = 1;
+        while (h->rb_fold <= top && !h->lv[h->rb_fold].rb) ++h->rb_fold;
+        PMG_CHECK(h->rb_fold <= top, PMG_ERR_ARG_WRONGSTATE, "row-block hierarchy without a row-block level (pmg_mgmc_set_level_rowblock)");
+        PMG_CHECK(h->rb_c0_starts[h->nranks] == h->lv[h->rb_fold - 1].n, PMG_ERR_ARG_SIZ, "the row blocks of the highest replicated level cover %lld rows, level %d has %d", (long long)h->rb_c0_starts[h->nranks], h->rb_fold - 1, h->lv[h->rb_fold - 1].n);
+      }
+      PMG_CHECK(l < h->rb_fold ? !Lv->rb : Lv->rb, PMG_ERR_ARG_WRONGSTATE, "row-block hierarchy: level %d %s", l, l < h->rb_fold ? "lies below a replicated level and must be replicated too" : "has no row block (pmg_mgmc_set_level_rowblock)");
       PMG_CHECK(h->coarse_type == 0, PMG_ERR_SUP, "row-block hierarchies: exact coarse sampler");
-      PMG_CHECK(l == 0 || (Lv->P_user.rp && Lv->R_user.rp && Lv->P_user.nr == Lv->rb_nowned && Lv->P_user.nc == h->lv[l - 1].n && Lv->R_user.nc == Lv->n), PMG_ERR_ARG_SIZ, "level %d: interpolation rows = owned rows, its columns and the restriction's in local numbering", l);
-      PMG_CHECK(l == 0 || Lv->R_user.nr == (l == 1 ? (int32_t)(h->rb_c0_starts[h->rank + 1] - h->rb_c0_starts[h->rank]) : h->lv[l - 1].rb_nowned), PMG_ERR_ARG_SIZ, "level %d: the restriction has one row per owned row of level %d", l, l - 1);
-      PMG_CHECK(l > 0 || h->rb_c0_starts[h->nranks] == Lv->n, PMG_ERR_ARG_SIZ, "the coarse row blocks cover %lld rows, the coarsest level has %d", (long long)h->rb_c0_starts[h->nranks], Lv->n);
+      if (l >= h->rb_fold) {
+        PMG_CHECK(Lv->P_user.rp && Lv->R_user.rp && Lv->P_user.nr == Lv->rb_nowned && Lv->P_user.nc == h->lv[l - 1].n && Lv->R_user.nc == Lv->n, PMG_ERR_ARG_SIZ, "level %d: interpolation rows = owned rows, its columns and the restriction's in local numbering", l);
+        PMG_CHECK(Lv->R_user.nr == (l == h->rb_fold ? (int32_t)(h->rb_c0_starts[h->rank + 1] - h->rb_c0_starts[h->rank]) : h->lv[l - 1].rb_nowned), PMG_ERR_ARG_SIZ, "level %d: the restriction has one row per owned row of level %d", l, l - 1);
+      } else
+        PMG_CHECK(l == 0 || (Lv->P_user.rp && Lv->P_user.nr == Lv->n && Lv->P_user.nc == h->lv[l - 1].n), PMG_ERR_ARG_SIZ, "interpolation of the replicated level %d missing or of the wrong shape", l);
     } else
       PMG_CHECK(l == 0 || (Lv->P_user.rp && Lv->P_user.nr == Lv->n && Lv->P_user.nc == h->lv[l - 1].n), PMG_ERR_ARG_SIZ, "interpolation of level %d missing or of the wrong shape", l);
     pos[l] = (int32_t *)malloc(sizeof(int32_t) * (size_t)Lv->n);
@@ -851,9 +877,20 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     U->P_nrows = U->P_user.nr;
     U->R_nrows = U->rb ? U->R_user.nr : R.nr;
     PMG_CALL(upload_transfer(&U->P_user, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
-    if (U->rb) /* the caller's rows of P^T: owned rows of level l-1 (on the replicated coarsest level: this rank's block of the global rows) */
-      PMG_CALL(upload_transfer(&U->R_user, pos[l - 1] + (l == 1 ? h->rb_c0_starts[h->rank] : 0), pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
-    else PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    if (!U->rb) PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    else /* the caller's rows of P^T: owned rows of level l-1 (on the replicated coarsest level: this rank's block of the global rows) */
+      PMG_CALL(upload_transfer(&U->R_user, pos[l - 1] + (l == h->rb_fold ? h->rb_c0_starts[h->rank] : 0), pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
+    if (U->rb && l == h->rb_fold && l - 1 >= 1) { /* the replicated level below keeps its vectors in a sliced-ELL layout: all-gather through natural order */
+      mg_level *Cc   = &h->lv[l - 1];
+      int32_t  *iota = (int32_t *)malloc(sizeof(int32_t) * (size_t)Cc->n);
+      PMG_CHECK(iota, PMG_ERR_MEM, "out of host memory");
+      for (int32_t q = 0; q < Cc->n; ++q) iota[q] = q;
+      pmg_status st = pmg_dev_upload((void **)&h->rb_fold_pos, pos[l - 1], sizeof(int32_t) * (size_t)Cc->n);
+      if (!st) st = pmg_dev_upload((void **)&h->rb_fold_iota, iota, sizeof(int32_t) * (size_t)Cc->n);
+      if (!st) st = pmg_dev_alloc((void **)&h->rb_fold_buf, sizeof(double) * (size_t)Cc->n);
+      free(iota);
+      PMG_CALL(st);
+    }
     hcsr_free(&R);
     if (h->lrc_k && U->rb) { /* row blocks: B_{l-1} = P_l^T B_l column by column on the device, with the V-cycle's own restriction */
       mg_level *Cc = &h->lv[l - 1];
@@ -864,23 +901,24 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
         double *bf = Bdev + (size_t)U->ld * c, *bc = Bc + (size_t)Cc->ld * c;
         PMG_CALL(pmg_distmcsor_refresh_layout(U->dm, bf, NULL)); /* the rows of P^T read other ranks' rows of B */
         PMG_KERNEL(pmgk_csr_spmv_rows(U->R_nrows, U->R_rowpos, U->R_rowptr, U->R_col, U->R_val, bf, bc, 0, NULL));
-        if (l == 1) { /* the replicated coarsest level takes the whole column */
-          int64_t cnts[64];
-          for (int r = 0; r < h->nranks; ++r) cnts[r] = h->rb_c0_starts[r + 1] - h->rb_c0_starts[r];
-          PMG_CALL(pmg_dist_allgather(h->rb_dist, bc, h->rb_c0_starts, cnts, NULL));
-        }
+        if (l == h->rb_fold) PMG_CALL(rb_fold_allgather(h, bc, NULL)); /* the replicated level below takes the whole column */
       }
       /* the refresh left copies on the ghost rows of the fine block: back to zeros there (B counts every row once) -- not
          needed any more, the block is dropped */
       pmg_dev_free(Bdev);
       Bdev = Bc;
-      if (l - 1 >= 1) PMG_CALL(pmg_distmcsor_set_lowrank_dev(Cc->dm, h->lrc_k, Bdev, h->lrc_S));
-      else {
-        double *B0 = (double *)malloc(sizeof(double) * (size_t)Cc->n * (size_t)h->lrc_k);
-        PMG_CHECK(B0, PMG_ERR_MEM, "out of host memory");
-        pmg_status st = hipMemcpy(B0, Bdev, sizeof(double) * (size_t)Cc->n * (size_t)h->lrc_k, hipMemcpyDeviceToHost) == hipSuccess ? PMG_SUCCESS : pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
-        if (!st) st = pmg_chol_create_csr_lowrank(Cc->n, Cc->A_user.rp, Cc->A_user.ci, Cc->A_user.v, h->lrc_k, B0, h->lrc_S, &h->chol);
-        free(B0);
+      if (l > h->rb_fold) PMG_CALL(pmg_distmcsor_set_lowrank_dev(Cc->dm, h->lrc_k, Bdev, h->lrc_S));
+      else { /* the highest replicated level: its whole block goes to the host in natural numbering, where the replicated levels below take over */
+        double *Bl = (double *)malloc(sizeof(double) * (size_t)Cc->ld * (size_t)h->lrc_k), *B0 = (double *)malloc(sizeof(double) * (size_t)Cc->n * (size_t)h->lrc_k);
+        PMG_CHECK(Bl && B0, PMG_ERR_MEM, "out of host memory");
+        pmg_status st = hipMemcpy(Bl, Bdev, sizeof(double) * (size_t)Cc->ld * (size_t)h->lrc_k, hipMemcpyDeviceToHost) == hipSuccess ? PMG_SUCCESS : pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
+        for (int32_t c = 0; c < h->lrc_k && !st; ++c)
+          for (int32_t r = 0; r < Cc->n; ++r) B0[(size_t)Cc->n * c + r] = Bl[(size_t)Cc->ld * c + pos[l - 1][r]];
+        free(Bl);
+        if (Bcur != h->lrc_B) free(Bcur);
+        Bcur = B0;
+        if (!st && l - 1 == 0) st = pmg_chol_create_csr_lowrank(Cc->n, Cc->A_user.rp, Cc->A_user.ci, Cc->A_user.v, h->lrc_k, Bcur, h->lrc_S, &h->chol);
+        else if (!st) st = level_attach_lrc(h, Cc, Bcur);
         PMG_CALL(st);
       }
     }
@@ -1513,11 +1551,7 @@ static pmg_status mg_restrict(pmg_mgmc h, int l, double *r_fine, double *b_coars
   } else {
     if (Lv->dm) PMG_CALL(pmg_distmcsor_refresh_layout(Lv->dm, r_fine, stream)); /* row block: the rows of P^T read r on other ranks' rows */
     PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, r_fine, b_coarse, 0, stream));
-    if (Lv->dm && l == 1) { /* the replicated coarsest level: every rank needs the whole right-hand side */
-      int64_t cnts[64];
-      for (int r = 0; r < h->nranks; ++r) cnts[r] = h->rb_c0_starts[r + 1] - h->rb_c0_starts[r];
-      PMG_CALL(pmg_dist_allgather(h->rb_dist, b_coarse, h->rb_c0_starts, cnts, stream));
-    }
+    if (Lv->dm && l == h->rb_fold) PMG_CALL(rb_fold_allgather(h, b_coarse, stream)); /* the replicated level below: every rank needs the whole right-hand side */
   }
   if (fold) {
     int64_t offs[64], cnts[64];
@@ -1807,6 +1841,9 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
   free(h->lrc_S);
   free(h->cuts);
   free(h->rb_c0_starts);
+  pmg_dev_free(h->rb_fold_pos);
+  pmg_dev_free(h->rb_fold_iota);
+  pmg_dev_free(h->rb_fold_buf);
   free(h->lv);
   free(h);
   *hp = NULL;

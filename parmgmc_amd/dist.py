@@ -665,12 +665,14 @@ class DistAIJMGMC:
     src/mc_sor.c:298-381).  `operators[l]` = global CSR triple of level l (0 = coarsest), `interpolations[l]` (l >= 1) =
     global CSR triple of the prolongation from level l-1 to level l -- what MGMC.from_hierarchy takes, available on every
     rank; `starts[l]` = the world+1 row-block boundaries of level l (default: equal blocks).  Every rank keeps its rows of
-    the levels >= 1 (plus one ghost row per row of another rank that its operator, restriction or the finer level's
-    interpolation reads) and the whole coarsest level, which is factored redundantly.  The whole sample loop -- colour
+    the levels with more than `replicate_below` rows (plus one ghost row per row of another rank that its operator,
+    restriction or the finer level's interpolation reads) and the WHOLE of the smaller levels -- at least the coarsest,
+    which is factored redundantly: there every rank runs the single-device kernels on identical data, which costs less
+    than a ghost update per colour for a few thousand rows.  The whole sample loop -- colour
     sweeps, ghost updates, residuals, transfers, coarse solve -- runs in C (pmg_mgmc.c) on the stream; this class only
     slices the matrices and builds the ghost plans (host set-up, collective).  Bit-identical to MGMC.from_hierarchy."""
 
-    def __init__(self, operators, interpolations, rank: int, world: int, group=None, transport=None, starts=None):
+    def __init__(self, operators, interpolations, rank: int, world: int, group=None, transport=None, starts=None, replicate_below: int = 50000):
         import ctypes as C
         import os
 
@@ -723,22 +725,33 @@ class DistAIJMGMC:
         rp0, ci0, v0 = a0.indptr.astype(np.int32), a0.indices.astype(np.int32), np.ascontiguousarray(a0.data)
         self._keep.append((rp0, ci0, v0))
         check(lib.pmg_mgmc_set_level_operator(self._h, 0, n[0], rp0.ctypes.data, ci0.ctypes.data, v0.ctypes.data))
-        cs = np.ascontiguousarray(self.starts[0], np.int64)
-        self._keep.append(cs)
-        check(lib.pmg_mgmc_set_rowblock_transport(self._h, self._drv._h, cs.ctypes.data))
         R = [None] + [P[l].T.tocsr() for l in range(1, L)]  # rows of P^T, entries by ascending fine row
         for m in R[1:]:
             m.sort_indices()
-        ghosts, nloc = [None] * L, [r1[l] - r0[l] for l in range(L)]
-        local_of = [None] * L  # global row -> local row of this rank (owned, then ghosts), -1 elsewhere; level 0: identity
-        local_of[0] = np.arange(n[0], dtype=np.int64)
-        for l in range(1, L):
+        fold = 1  # lowest row-block level; the levels below are replicated
+        while fold < L - 1 and n[fold] <= replicate_below:
+            fold += 1
+        self.fold = fold
+        cs = np.ascontiguousarray(self.starts[fold - 1], np.int64)  # who restricts which rows of the highest replicated level
+        self._keep.append(cs)
+        check(lib.pmg_mgmc_set_rowblock_transport(self._h, self._drv._h, cs.ctypes.data))
+        ghosts, nloc = [np.zeros(0, np.int64)] * L, [r1[l] - r0[l] for l in range(L)]
+        local_of = [None] * L  # global row -> local row of this rank (owned, then ghosts), -1 elsewhere; replicated levels: identity
+        for l in range(fold):
+            local_of[l] = np.arange(n[l], dtype=np.int64)
+            if l >= 1:  # replicated level: the whole operator and interpolation, as MGMC.from_hierarchy takes them
+                rp, ci, v = (np.ascontiguousarray(a_, t_) for a_, t_ in zip(operators[l], (np.int32, np.int32, np.float64)))
+                prp, pci, pv = (np.ascontiguousarray(a_, t_) for a_, t_ in zip(interpolations[l], (np.int32, np.int32, np.float64)))
+                self._keep += [rp, ci, v, prp, pci, pv]
+                check(lib.pmg_mgmc_set_level_operator(self._h, l, n[l], rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+                check(lib.pmg_mgmc_set_level_interpolation(self._h, l, n[l], n[l - 1], prp.ctypes.data, pci.ctypes.data, pv.ctypes.data))
+        for l in range(fold, L):
             Al = A[l]
             mc = MCSOR(Al.indptr.astype(np.int32), Al.indices.astype(np.int32), Al.data).setup()  # the global colouring, on the device's host code
             col, ncol = mc.get_coloring(), mc.get_num_colors()
             mc.destroy()
             mine = Al[r0[l]:r1[l]]
-            extra = [R[l][r0[l - 1]:r1[l - 1]].indices.astype(np.int64)]  # fine rows my restriction rows read
+            extra = [R[l][r0[l - 1]:r1[l - 1]].indices.astype(np.int64)]  # fine rows my restriction rows read (level l-1 replicated: the block I restrict into)
             if l + 1 < L:
                 extra.append(P[l + 1][r0[l + 1]:r1[l + 1]].indices.astype(np.int64))  # rows of this level the finer level's interpolation reads
             ghosts[l], plan = rowblock_plan(mine.indices, r0[l], r1[l], n[l], col[r0[l]:r1[l]], ncol, np.concatenate(extra), rank, world, group)
@@ -757,13 +770,13 @@ class DistAIJMGMC:
             check(lib.pmg_mgmc_set_level_operator(self._h, l, nloc[l] + ng, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
             check(lib.pmg_mgmc_set_level_rowblock(self._h, l, r0[l], nloc[l], ncol, cols.ctypes.data, plan["send_ptr"].ctypes.data, plan["send_rows"].ctypes.data, plan["counts"].ctypes.data,
                                                   plan["recv_ptr"].ctypes.data, plan["recv_src"].ctypes.data, plan["recv_rows"].ctypes.data))
-        for l in range(1, L):
+        for l in range(fold, L):
             pm = P[l][r0[l]:r1[l]]  # my rows of P_l (entries in the caller's order), columns -> local numbering of level l-1
             prp, pci, pv = pm.indptr.astype(np.int32), local_of[l - 1][pm.indices].astype(np.int32), np.ascontiguousarray(pm.data)
             rm = R[l][r0[l - 1]:r1[l - 1]]  # the rows of P_l^T I own on level l-1, columns -> local numbering of level l
             rrp, rci, rv = rm.indptr.astype(np.int32), local_of[l][rm.indices].astype(np.int32), np.ascontiguousarray(rm.data)
             assert pci.min(initial=0) >= 0 and rci.min(initial=0) >= 0, "a transfer reads a row that is neither owned nor a ghost"
-            ncl = n[0] if l == 1 else nloc[l - 1] + len(ghosts[l - 1])
+            ncl = n[l - 1] if l == fold else nloc[l - 1] + len(ghosts[l - 1])
             self._keep += [prp, pci, pv, rrp, rci, rv]
             check(lib.pmg_mgmc_set_level_interpolation(self._h, l, nloc[l], ncl, prp.ctypes.data, pci.ctypes.data, pv.ctypes.data))
             check(lib.pmg_mgmc_set_level_restriction(self._h, l, len(rrp) - 1, nloc[l] + len(ghosts[l]), rrp.ctypes.data, rci.ctypes.data, rv.ctypes.data))
