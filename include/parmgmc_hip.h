@@ -324,14 +324,16 @@ pmg_status pmg_mgmc_set_level_operator(pmg_mgmc mg, int32_t level, int32_t n, co
 pmg_status pmg_mgmc_set_level_interpolation(pmg_mgmc mg, int32_t level, int32_t nrows, int32_t ncols, const int32_t *rowptr_host, const int32_t *colidx_host, const double *vals_host);
 /* Caller-supplied hierarchy distributed by ROW BLOCKS over the ranks of `dist` (any pmg_dist object: only its transport is
    used), the reference's PCGAMGMC on a MATMPIAIJ (src/pc_gamgmc.c:157-223 with MCSORApply_MPIAIJ, src/mc_sor.c:298-381, as
-   the level sampler).  Level 0 (exact sampler) is passed whole on every rank and factored redundantly; its right-hand side
-   is all-gathered by the row blocks coarse_starts[0 .. nranks].  A level l >= 1 is this rank's rows in LOCAL numbering
+   the level sampler).  The levels 0 .. F-1 are REPLICATED: passed whole on every rank (pmg_mgmc_set_level_operator /
+   _interpolation as for one device; level 0 is the exact sampler, factored redundantly) and run with the single-device
+   kernels on identical data; the right-hand side of level F-1 is all-gathered by the row blocks coarse_starts[0 .. nranks]
+   of THAT level.  F >= 1 is the lowest level that has a row block.  A row-block level l >= F is this rank's rows in LOCAL numbering
    (pmg_mgmc_set_level_operator: owned rows in global order with their entries in global CSR order, then one identity row
    per ghost = every row of another rank that this rank's operator, restriction or the finer level's interpolation reads)
    plus pmg_mgmc_set_level_rowblock: global row of local row 0, number of owned rows, a globally valid distance-1 colouring
    of the owned rows, and the ghost-update plan of pmg_distmcsor_create with LOCAL ROW indices in place of layout
    positions.  pmg_mgmc_set_level_interpolation(l) then takes the owned rows of P_l with columns in the local numbering of
-   level l-1 (global for l-1 = 0) and pmg_mgmc_set_level_restriction(l) the rows of P_l^T this rank owns on level l-1,
+   level l-1 (global for the replicated level F-1) and pmg_mgmc_set_level_restriction(l) the rows of P_l^T this rank owns on level l-1,
    columns in the local numbering of level l, entries by ascending global fine row.  pmg_mgmc_sample's vectors have one
    entry per local row of the finest level (ghost entries ignored / undefined).  Same bits as the single-device chain of
    pmg_mgmc_create_hierarchy with the same colouring.  pmg_mgmc_set_lowrank takes this rank's rows of B (n_local x k, ghost
