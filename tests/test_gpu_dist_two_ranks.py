@@ -457,3 +457,66 @@ def test_row_block_sampler_with_a_low_rank_update(world, sweep_type):
     yp = torch.as_tensor(y_all, device="cuda")
     plain.sample(torch.as_tensor(b_all, device="cuda"), yp, its, seed=42, counter0=1)
     assert np.abs(yp.cpu().numpy() - ref).max() / np.abs(ref).max() > 1e-6
+
+
+def _chain_of_objects_worker(rank, world, port, shapes, q):
+    """several sampler objects one after the other in ONE process, as bench.py builds them: every one gets the pooled
+    receive block of its predecessor (zeroed) and the peers' kept mappings"""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from parmgmc_amd.dist import DistGridSampler
+
+    out = []
+    for it, (nx, ny, nz, sweeps) in enumerate(shapes):
+        smp = DistGridSampler(nx, ny, nz, 1.5, rank, world, omega=1.0, sweep_type=1, transport="ipc")
+        assert smp.transport == "ipc"
+        g = smp.grid
+        rng = np.random.default_rng(5 + it)
+        b_all, y_all = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
+        lo, hi = g.kz0 * nx * ny, (g.kz0 + g.nz) * nx * ny
+        b = g.to_cvec(torch.as_tensor(b_all[lo:hi], device="cuda"))
+        y = g.to_cvec(torch.as_tensor(y_all[lo:hi], device="cuda"))
+        smp.sample_cvec(b, y, sweeps, seed=42, counter0=1)
+        torch.cuda.synchronize()
+        out.append(g.from_cvec(y).cpu().numpy())
+        smp.destroy()  # collective: disconnect, barrier, back to the pool
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_chain_of_ipc_objects_in_one_process_reuses_its_receive_block():
+    """The ipc receive block holds sequence numbers that only grow.  A second object that inherits the block of the first
+    (pmg_dist.c pools the blocks; before, the allocator could hand the same memory back) must start from zeros: the first
+    object here runs 40 sweeps, so its flag words stand at 80 when the second one, with the same block size, begins to wait
+    for 1, 2, 3 ...  Three objects, two shapes (two pool entries), 3 ranks: every chain bit-identical to one device."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from parmgmc_amd import GridMCSOR
+
+    shapes = [(40, 18, 12, 40), (40, 18, 12, 3), (24, 10, 9, 5), (40, 18, 12, 2)]
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chain_of_objects_worker, args=(r, world, port, shapes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = sorted((q.get(timeout=200) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for it, (nx, ny, nz, sweeps) in enumerate(shapes):
+        rng = np.random.default_rng(5 + it)
+        b_all, y_all = rng.standard_normal(nx * ny * nz), rng.standard_normal(nx * ny * nz)
+        one = GridMCSOR(nx, ny, nz, 1.5)
+        yd = torch.as_tensor(y_all, device="cuda")
+        one.sample(torch.as_tensor(b_all, device="cuda"), yd, sweeps, seed=42, counter0=1)
+        got = np.concatenate([x[1][it] for x in parts])
+        assert np.array_equal(got, yd.cpu().numpy()), f"object {it} of the chain"
