@@ -432,16 +432,47 @@ struct rr_line {
   d2 ev, od;
 };
 
-__device__ __forceinline__ rr_line rr_load_line(const double *__restrict__ v, uint32_t base, uint32_t cs8, int parity)
+// where the fine plane g (GLOBAL index) of a vector lives: in the cvec itself (the slab's planes and its two ghost planes),
+// or -- z-slabs only -- in one of the two extra planes lo2 / hi2 (the planes kz0 - 2 and kz0 + nz + 1: colour 0, then colour 1,
+// sp doubles each), which the residual of a ghost plane reads.  Wave-uniform.
+struct rr_planes {
+  const double *v, *lo2, *hi2;
+  int           kz0, nz;
+  uint32_t      sp8, cs8;
+};
+struct rr_plane {
+  const double *p;
+  uint32_t      base, cst;
+};
+__device__ __forceinline__ rr_plane rr_plane_of(const rr_planes &P, int g)
 {
-  const uint32_t c = parity ? cs8 : 0u;
-  rr_line        r;
-  r.ev = ld2(at_bytes(v, base + c));
-  r.od = ld2(at_bytes(v, base + (cs8 - c)));
+  const int kl = g - P.kz0; // plane inside the slab
+  rr_plane  r;
+  if (kl >= -1 && kl <= P.nz) {
+    r.p    = P.v;
+    r.base = (uint32_t)(kl + 1) * P.sp8;
+    r.cst  = P.cs8;
+  } else {
+    r.p    = kl < 0 ? P.lo2 : P.hi2;
+    r.base = 0;
+    r.cst  = P.sp8;
+  }
   return r;
 }
 
-__global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_layout L, pmgk_grid_op op, pmgk_st27_dims C, int tplE, int wpp, int kc, int nchunks, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ bc)
+__device__ __forceinline__ rr_line rr_load_line(const rr_plane &pl, uint32_t line, int parity)
+{
+  const uint32_t c = parity ? pl.cst : 0u;
+  rr_line        r;
+  r.ev = ld2(at_bytes(pl.p, pl.base + line + c));
+  r.od = ld2(at_bytes(pl.p, pl.base + line + (pl.cst - c)));
+  return r;
+}
+
+// L, C: fine layout and coarse extents of this rank (a single device: kz0 = 0, nz = nzg, ylo2 = yhi2 = NULL).  A z-slab
+// restricts into the coarse planes it owns (K with fine plane 2K on this rank): it needs the residual on its two ghost
+// planes, i.e. y two planes deep (ylo2, yhi2) and b on the ghost planes.
+__global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_layout L, pmgk_grid_op op, pmgk_st27_dims C, int tplE, int wpp, int kc, int nchunks, const double *__restrict__ b, const double *__restrict__ y, const double *__restrict__ ylo2, const double *__restrict__ yhi2, double *__restrict__ bc)
 {
   const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3, per = (int)gridDim.x >> 3;
   const int gw  = __builtin_amdgcn_readfirstlane((xcd * per + q) * 4 + (int)(threadIdx.x >> 6));
@@ -467,26 +498,29 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
   T.oE1    = i0 + 3 < L.nx - 1;
   T.oV1    = i0 + 3 < L.nx;
   T.ovalid = i0 + 1 < L.nx;
-  const int      K0 = zc * kc, K1 = min(K0 + kc, C.nz);
-  const int      kfirst = max(2 * K0 - 1, 0), klast = min(2 * K1 - 1, L.nzg - 1), jmax = L.ny - 1;
-  const uint32_t sx8 = 8u * (uint32_t)L.sx, cs8 = 8u * (uint32_t)L.cs, sp8 = 8u * (uint32_t)L.sp;
+  const int      K0 = C.kz0 + zc * kc, K1 = min(K0 + kc, C.kz0 + C.nz); // coarse planes of this chunk (global)
+  const int      kfirst = max(2 * K0 - 1, 0), klast = min(2 * K1 - 1, L.nzg - 1), jmax = L.ny - 1; // fine planes (global)
+  const uint32_t sx8 = 8u * (uint32_t)L.sx;
+  const rr_planes PY = {y, ylo2, yhi2, L.kz0, L.nz, 8u * (uint32_t)L.sp, 8u * (uint32_t)L.cs};
+  const rr_planes PB = {b, b, b, L.kz0, L.nz, 8u * (uint32_t)L.sp, 8u * (uint32_t)L.cs}; // b is read on residual planes only: never beyond the ghost planes
   const double   ma = -op.h2;
   rr_acc         a = {0.0, 0.0}, n = {0.0, 0.0};
-  double        *out = bc + I0 + (int64_t)C.nx * (Jc + (int64_t)C.ny * (K0 + 1));
+  double        *out = bc + I0 + (int64_t)C.nx * (Jc + (int64_t)C.ny * (K0 - C.kz0 + 1));
   const int64_t  cplane = (int64_t)C.nx * C.ny;
   rr_line        Dv[3], Cv[3], Uv[3], hS, hN; // hS, hN: the lines 2J-2 and 2J+2 of the plane k (S of the first line, N of the last)
   {
-    const int kd = max(kfirst - 1, 0);
+    const int      kd = max(kfirst - 1, 0);
+    const rr_plane pd = rr_plane_of(PY, kd), pc = rr_plane_of(PY, kfirst);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int      jc = min(max(2 * Jc - 1 + i, 0), jmax);
       const uint32_t ln = (uint32_t)jc * sx8 + T.lo;
-      Dv[i] = rr_load_line(y, (uint32_t)(kd + 1) * sp8 + ln, cs8, (jc + kd) & 1);
-      Cv[i] = rr_load_line(y, (uint32_t)(kfirst + 1) * sp8 + ln, cs8, (jc + kfirst) & 1);
+      Dv[i] = rr_load_line(pd, ln, (jc + kd) & 1);
+      Cv[i] = rr_load_line(pc, ln, (jc + kfirst) & 1);
     }
     const int jS = min(max(2 * Jc - 2, 0), jmax), jN = min(max(2 * Jc + 2, 0), jmax);
-    hS = rr_load_line(y, (uint32_t)(kfirst + 1) * sp8 + (uint32_t)jS * sx8 + T.lo, cs8, (jS + kfirst) & 1);
-    hN = rr_load_line(y, (uint32_t)(kfirst + 1) * sp8 + (uint32_t)jN * sx8 + T.lo, cs8, (jN + kfirst) & 1);
+    hS = rr_load_line(pc, (uint32_t)jS * sx8 + T.lo, (jS + kfirst) & 1);
+    hN = rr_load_line(pc, (uint32_t)jN * sx8 + T.lo, (jN + kfirst) & 1);
   }
   for (int k = kfirst; k <= klast; ++k) {
     int J = Jc; // per plane: what depends on the lines alone would otherwise be kept in registers across the march
@@ -495,21 +529,21 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
     const int      nzc = (int)hasD + (int)hasU, ku = hasU ? k + 1 : k;
     const double   dg2 = uniform(op.diag[nzc + 2]), dg3 = uniform(op.diag[nzc + 3]), dg4 = uniform(op.diag[nzc + 4]);
     const double   wz = odd ? 0.5 : 1.0;
-    const uint32_t pl = (uint32_t)(k + 1) * sp8, plu = (uint32_t)(ku + 1) * sp8;
+    const rr_plane pu = rr_plane_of(PY, ku), pb = rr_plane_of(PB, k);
     // the lines beside the thread's three are fetched a plane ahead like its own: in the step in which their owners load
     // them, so that one of the two requests finds the line in the L2
     const int      jS = min(max(2 * J - 2, 0), jmax), jN = min(max(2 * J + 2, 0), jmax);
-    const rr_line  hSu = rr_load_line(y, plu + (uint32_t)jS * sx8 + T.lo, cs8, (jS + ku) & 1);
-    const rr_line  hNu = rr_load_line(y, plu + (uint32_t)jN * sx8 + T.lo, cs8, (jN + ku) & 1);
+    const rr_line  hSu = rr_load_line(pu, (uint32_t)jS * sx8 + T.lo, (jS + ku) & 1);
+    const rr_line  hNu = rr_load_line(pu, (uint32_t)jN * sx8 + T.lo, (jN + ku) & 1);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int      jc = min(max(2 * J - 1 + i, 0), jmax);
-      Uv[i] = rr_load_line(y, plu + (uint32_t)jc * sx8 + T.lo, cs8, (jc + ku) & 1);
+      Uv[i] = rr_load_line(pu, (uint32_t)jc * sx8 + T.lo, (jc + ku) & 1);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int      j = 2 * J - 1 + i, jc = min(max(j, 0), jmax);
-      const rr_line  bb = rr_load_line(b, pl + (uint32_t)jc * sx8 + T.lo, cs8, (jc + k) & 1);
+      const rr_line  bb = rr_load_line(pb, (uint32_t)jc * sx8 + T.lo, (jc + k) & 1);
       const rr_line &S = i == 0 ? hS : Cv[i > 0 ? i - 1 : 0], &N = i == 2 ? hN : Cv[i < 2 ? i + 1 : 2];
       const bool     hasS = jc > 0, hasN = jc < jmax, inner = hasS && hasN;
       residual_consts Kc;
@@ -681,24 +715,30 @@ extern "C" int pmgk_grid_residual(const pmgk_grid_layout *L, const pmgk_grid_op 
   return launch_status();
 }
 
-// b_coarse = P^T (b - A y) in one launch; returns -1 (nothing launched) where the fused kernel does not apply: z-slabs,
-// semicoarsened or permuted coarse levels
-extern "C" int pmgk_grid_residual_restrict(const pmgk_grid_layout *L, const pmgk_grid_op *op, const pmgk_st27_dims *C, const double *b, const double *y, double *bc, void *stream)
+// b_coarse = P^T (b - A y) in one launch; returns -1 (nothing launched) where the fused kernel does not apply: semicoarsened
+// or permuted coarse levels, even extents.  A z-slab (L->kz0, L->nz; C: the coarse planes it owns) passes y's planes
+// kz0 - 2 and kz0 + nz + 1 in ylo2 / yhi2 (colour 0 plane, then colour 1 plane; NULL at a domain face) and needs b and y
+// current on the ghost planes; a single device passes NULL.
+extern "C" int pmgk_grid_residual_restrict(const pmgk_grid_layout *L, const pmgk_grid_op *op, const pmgk_st27_dims *C, const double *b, const double *y, const double *ylo2, const double *yhi2, double *bc, void *stream)
 {
   static const int off    = getenv("PMG_GRID_FUSED_RR") ? !atoi(getenv("PMG_GRID_FUSED_RR")) : 0;
   static const int kc_env = getenv("PMG_GRID_RR_CHUNK") ? atoi(getenv("PMG_GRID_RR_CHUNK")) : 0;
   const int        tplE   = grid_threads_per_line(L);
-  if (off || L->kz0 != 0 || L->nz != L->nzg || C->kz0 != 0 || C->nz != C->nzg) return -1;
+  const bool       slab   = L->kz0 != 0 || L->nz != L->nzg;
+  if (off || C->nz <= 0) return -1;
+  if (!slab && (C->kz0 != 0 || C->nz != C->nzg)) return -1;
+  if (slab && ((L->kz0 > 0 && !ylo2) || (L->kz0 + L->nz < L->nzg && !yhi2) || L->nz < 2)) return -1;
   if (L->nx < 3 || L->ny < 3 || L->nzg < 3 || !(L->nx & 1) || !(L->ny & 1) || !(L->nzg & 1)) return -1;
   if (C->nx != (L->nx + 1) / 2 || C->ny != (L->ny + 1) / 2 || C->nzg != (L->nzg + 1) / 2) return -1;
   if (tplE != (C->nx + 1) / 2 || (int64_t)C->ny * tplE >= ((int64_t)1 << 30)) return -1;
   if (2 * (int64_t)L->cs * 8 >= ((int64_t)1 << 32)) return -1; // 32-bit byte offsets inside a vector
+  if (slab && (2 * C->kz0 < L->kz0 || 2 * (C->kz0 + C->nz - 1) >= L->kz0 + L->nz)) return -1; // a coarse plane belongs to the owner of its fine plane
   const int     wpp = (int)(((int64_t)C->ny * tplE + 61) / 62);
   int           kc  = kc_env > 0 ? kc_env : 8; // coarse planes per chunk: each chunk re-reads one fine plane
   while (kc_env <= 0 && kc > 2 && (int64_t)wpp * ((C->nz + kc - 1) / kc) < 2048) kc >>= 1;
   const int     nchunks = (C->nz + kc - 1) / kc;
   const int64_t nblocks = ((int64_t)wpp * nchunks + 3) / 4;
-  hipLaunchKernelGGL(grid_residual_restrict_kernel, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, *L, *op, *C, tplE, wpp, kc, nchunks, b, y, bc);
+  hipLaunchKernelGGL(grid_residual_restrict_kernel, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, *L, *op, *C, tplE, wpp, kc, nchunks, b, y, ylo2, yhi2, bc);
   return launch_status();
 }
 

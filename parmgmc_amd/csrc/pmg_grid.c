@@ -327,14 +327,14 @@ pmg_status pmg_grid_residual_cvec(pmg_grid g, const double *b, const double *y, 
   return PMG_SUCCESS;
 }
 
-pmg_status pmg_grid_residual_restrict(pmg_grid g, const double *b, const double *y, const pmgk_st27_dims *C, double *b_coarse, int *done, void *stream)
+pmg_status pmg_grid_residual_restrict(pmg_grid g, const double *b, const double *y, const double *ylo2, const double *yhi2, const pmgk_st27_dims *C, double *b_coarse, int *done, void *stream)
 {
   PMG_CHECK(g && b && y && C && b_coarse && done, PMG_ERR_ARG_NULL, "null argument");
   *done = 0;
   if (g->lrc) return PMG_SUCCESS;
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, 0, 0, 0, 0);
-  const int rc = pmgk_grid_residual_restrict(&g->L, &op, C, b, y, b_coarse, stream);
+  const int rc = pmgk_grid_residual_restrict(&g->L, &op, C, b, y, ylo2, yhi2, b_coarse, stream);
   if (rc < 0) return PMG_SUCCESS;
   PMG_CHECK(rc == 0, PMG_ERR_GPU, "kernel launch failed: pmgk_grid_residual_restrict");
   *done = 1;

@@ -44,7 +44,7 @@ pmg_status pmg_grid_sweep_color_faces_cvec(pmg_grid g, int color, int noisy, int
 /* kernel-side description of a grid object (internal) */
 pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L);
 /* residual and Q1 restriction fused; *done = 0 when the fused kernel does not apply (the caller runs the two steps) */
-pmg_status pmg_grid_residual_restrict(pmg_grid g, const double *b, const double *y, const pmgk_st27_dims *C, double *b_coarse, int *done, void *stream);
+pmg_status pmg_grid_residual_restrict(pmg_grid g, const double *b, const double *y, const double *ylo2, const double *yhi2, const pmgk_st27_dims *C, double *b_coarse, int *done, void *stream);
 
 #define PMG_XCH_MAXSEG 4
 /* low-rank (MATLRC) helper shared by pmg_mcsor and pmg_grid (pmg_lrc.c); vectors in the sampler's layout */

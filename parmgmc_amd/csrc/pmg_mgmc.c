@@ -43,6 +43,8 @@ typedef struct {
   int64_t   ld;
   double   *b, *x, *r;
   int       x_unset; /* the iterate is zero but the memset was skipped: the next out-of-place sweep starts from NULL */
+  double   *y2lo, *y2hi; /* z-slab grid level: the iterate's planes kz0 - 2 and kz0 + nz + 1 (colour 0 plane, colour 1 plane) for the fused residual + restriction */
+  int       rr_slab;     /* ... which every rank can run (agreed from the slab cuts) */
   double   *x2; /* second buffer of the out-of-place class-stencil sweep (single-device levels): x and x2 swap after every directional sweep */
   /* transfers to the next coarser level, in layout numbering on the device */
   int32_t  P_nrows, R_nrows;
@@ -1422,6 +1424,22 @@ static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
     PMG_HIP(hipMemset(Lv->x, 0, sizeof(double) * (size_t)Lv->ld));
     PMG_HIP(hipMemset(Lv->r, 0, sizeof(double) * (size_t)Lv->ld));
     if (st27_use_pair(Lv) || st27_use_pair_slab(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld)); /* zero-filled: the ghost planes stay zero */
+    if (l >= 1 && Lv->is_grid && Lv->distributed && Lv->grid_transfer && !Lv->cpos_dev && !h->lrc_k && !(getenv("PMG_GRID_FUSED_RR_SLAB") && !atoi(getenv("PMG_GRID_FUSED_RR_SLAB")))) {
+      /* the fused residual + restriction on a z-slab: every rank needs two planes (it hands its second and second-to-last
+         ones to the neighbours) and a coarse plane of its own; decided from the cuts, identically on every rank */
+      const int32_t *fc = h->cuts + (size_t)l * (size_t)(h->nranks + 1), *cc = h->cuts + (size_t)(l - 1) * (size_t)(h->nranks + 1);
+      int            ok = 1;
+      for (int r = 0; r < h->nranks; ++r) ok = ok && fc[r + 1] - fc[r] >= 2 && cc[r + 1] - cc[r] >= 1;
+      if (ok) {
+        int64_t own, ghost, np;
+        PMG_CALL(pmg_grid_halo_plane(Lv->g, 0, 0, &own, &ghost, &np));
+        PMG_CALL(pmg_dev_alloc((void **)&Lv->y2lo, sizeof(double) * 2 * (size_t)np));
+        PMG_CALL(pmg_dev_alloc((void **)&Lv->y2hi, sizeof(double) * 2 * (size_t)np));
+        PMG_HIP(hipMemset(Lv->y2lo, 0, sizeof(double) * 2 * (size_t)np));
+        PMG_HIP(hipMemset(Lv->y2hi, 0, sizeof(double) * 2 * (size_t)np));
+        Lv->rr_slab = 1;
+      }
+    }
   }
   PMG_CALL(pmg_dev_alloc((void **)&h->y_lay, sizeof(double) * (size_t)F->ld));
   PMG_CALL(pmg_dev_alloc((void **)&h->b_lay, sizeof(double) * (size_t)F->ld));
@@ -1565,6 +1583,50 @@ static pmg_status mg_restrict(pmg_mgmc h, int l, double *r_fine, double *b_coars
   return PMG_SUCCESS;
 }
 
+/* z-slab grid level: b_coarse = P^T (b - A x) in one kernel.  The residual on the two ghost planes needs x two planes deep:
+   every rank sends its second and second-to-last planes (both colours, one exchange) into the neighbours' y2 buffers; b is
+   current on its ghost planes (pmg_mgmc_sample exchanges them once per call: in-place form only).  The coarse planes
+   this rank owns, the fold into a replicated coarse level and the all-gather behind it are those of mg_restrict. */
+static pmg_status mg_residual_restrict_slab(pmg_mgmc h, int l, void *stream)
+{
+  mg_level      *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
+  pmgk_st27_dims CD   = level_dims(Cc);
+  double        *bc   = Cc->b;
+  const int      fold = !Cc->distributed;
+  const int32_t *cc   = h->cuts + (size_t)(l - 1) * (size_t)(h->nranks + 1);
+  const double  *slo[2], *shi[2];
+  double        *rlo[2], *rhi[2];
+  int64_t        n[2];
+  for (int c = 0; c < 2; ++c) {
+    int64_t own, ghost;
+    PMG_CALL(pmg_grid_halo_plane(Lv->g, c, 0, &own, &ghost, &n[c]));
+    slo[c] = Lv->x + own + n[c]; /* plane 1 */
+    rlo[c] = Lv->y2lo + (int64_t)c * n[c];
+    PMG_CALL(pmg_grid_halo_plane(Lv->g, c, 1, &own, &ghost, &n[c]));
+    shi[c] = Lv->x + own - n[c]; /* plane nz - 2 */
+    rhi[c] = Lv->y2hi + (int64_t)c * n[c];
+  }
+  PMG_CALL(pmg_dist_exchange(h->dist, 2, slo, n, rlo, n, shi, n, rhi, n, stream));
+  if (fold) {
+    CD.kz0 = cc[h->rank];
+    CD.nz  = cc[h->rank + 1] - cc[h->rank];
+    bc     = Cc->b + Cc->off * CD.kz0;
+  }
+  int done = 0;
+  PMG_CALL(pmg_grid_residual_restrict(Lv->g, Lv->b, Lv->x, Lv->kz0 > 0 ? Lv->y2lo : NULL, Lv->kz0 + Lv->nzl < Lv->nz ? Lv->y2hi : NULL, &CD, bc, &done, stream));
+  PMG_CHECK(done, PMG_ERR_PLIB, "level %d: the fused residual + restriction refused a slab the set-up had accepted", l);
+  if (fold) {
+    int64_t offs[64], cnts[64];
+    PMG_CHECK(h->nranks <= 64, PMG_ERR_ARG_OUTOFRANGE, "too many ranks");
+    for (int r = 0; r < h->nranks; ++r) {
+      offs[r] = Cc->off * ((int64_t)cc[r] + 1);
+      cnts[r] = Cc->off * (int64_t)(cc[r + 1] - cc[r]);
+    }
+    PMG_CALL(pmg_dist_allgather(h->dist, Cc->b, offs, cnts, stream));
+  }
+  return PMG_SUCCESS;
+}
+
 /* x_fine += P_l e_coarse (MatInterpolateAdd).  only_color (grid level): -1 = both colours, else just that one. */
 static pmg_status mg_prolong_add(pmg_mgmc h, int l, const double *e_coarse, double *x_fine, int only_color, void *stream)
 {
@@ -1605,8 +1667,12 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev) { /* b_{l-1} = P^T (b - A x) in one pass */
       const pmgk_st27_dims CD = level_dims(Cc);
       int                  done = 0;
-      PMG_CALL(pmg_grid_residual_restrict(Lv->g, Lv->b, Lv->x, &CD, Cc->b, &done, stream));
+      PMG_CALL(pmg_grid_residual_restrict(Lv->g, Lv->b, Lv->x, NULL, NULL, &CD, Cc->b, &done, stream));
       if (done) continue;
+    }
+    if (Lv->is_grid && Lv->rr_slab && Lv->b == h->b_lay) { /* z-slab, in-place form: b's ghost planes are current */
+      PMG_CALL(mg_residual_restrict_slab(h, l, stream));
+      continue;
     }
     if (Lv->is_grid) PMG_CALL(pmg_grid_residual_cvec(Lv->g, Lv->b, Lv->x, Lv->r, stream));
     else if (Lv->is_st27) {
@@ -1662,6 +1728,7 @@ pmg_status pmg_mgmc_sample(pmg_mgmc h, const double *b_nat, double *y_nat, int32
   PMG_CALL(lvl_to_layout(F, b_nat, h->b_lay, stream));
   PMG_CALL(lvl_to_layout(F, y_nat, h->y_lay, stream));
   if (h->correction_form && F->distributed) PMG_CALL(halo_level(h, F, h->y_lay, stream)); /* the outer residual reads the ghost planes of y */
+  if (!h->correction_form && F->rr_slab) PMG_CALL(halo_level(h, F, h->b_lay, stream));     /* the fused residual + restriction reads b on the ghost planes */
   if (h->correction_form && F->dm) PMG_CALL(pmg_distmcsor_refresh_layout(F->dm, h->y_lay, stream)); /* ... the ghost rows of a row block */
   for (int32_t it = 0; it < its; ++it) {
     if (!h->correction_form) {
@@ -1785,7 +1852,7 @@ pmg_status pmg_mgmc_level_residual_restrict(pmg_mgmc h, int32_t level, const dou
   int done = 0;
   if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev) {
     const pmgk_st27_dims CD = level_dims(&h->lv[level - 1]);
-    PMG_CALL(pmg_grid_residual_restrict(Lv->g, b_lvl, x_lvl, &CD, b_coarse, &done, stream));
+    PMG_CALL(pmg_grid_residual_restrict(Lv->g, b_lvl, x_lvl, NULL, NULL, &CD, b_coarse, &done, stream));
   }
   PMG_CHECK(done, PMG_ERR_SUP, "level %d: no fused residual + restriction (z-slab, low-rank update, permuted or semicoarsened coarse level)", level);
   return PMG_SUCCESS;
@@ -1813,6 +1880,8 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
     pmg_dev_free(Lv->x);
     pmg_dev_free(Lv->r);
     pmg_dev_free(Lv->x2);
+    pmg_dev_free(Lv->y2lo);
+    pmg_dev_free(Lv->y2hi);
     pmg_dev_free(Lv->cpos_dev);
     pmg_dev_free(Lv->st_coef);
     pmg_dev_free(Lv->st_idiag);
