@@ -327,11 +327,12 @@ pmg_status pmg_grid_residual_cvec(pmg_grid g, const double *b, const double *y, 
   return PMG_SUCCESS;
 }
 
+pmg_lrc pmg_grid_lrc(pmg_grid g) { return g ? g->lrc : NULL; }
+
 pmg_status pmg_grid_residual_restrict(pmg_grid g, const double *b, const double *y, const double *ylo2, const double *yhi2, const pmgk_st27_dims *C, double *b_coarse, int *done, void *stream)
 {
   PMG_CHECK(g && b && y && C && b_coarse && done, PMG_ERR_ARG_NULL, "null argument");
-  *done = 0;
-  if (g->lrc) return PMG_SUCCESS;
+  *done = 0; /* a low-rank term is the caller's: pmg_lrc_residual_sub_restricted with pmg_grid_lrc(g) */
   pmgk_grid_op op;
   pmg_grid_fill_op(g, &op, 0, 0, 0, 0);
   const int rc = pmgk_grid_residual_restrict(&g->L, &op, C, b, y, ylo2, yhi2, b_coarse, stream);

@@ -57,6 +57,8 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
 pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream); /* after the sweep that used the vector pmg_lrc_rhs returned */
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream);
+pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc l_fine, pmg_lrc l_coarse, const double *x_fine_lay, double *b_coarse_lay, void *stream);
+pmg_lrc    pmg_grid_lrc(pmg_grid g); /* the grid operator's low-rank update, NULL if none (borrowed) */
 void       pmg_lrc_destroy(pmg_lrc *l);
 pmg_status pmg_mcsor_set_idiag_by_division(pmg_mcsor mc, int on); /* PCPARSOR's idiag = omega / d */
 /* pmg_parsor.c: data-flow form of PCPARSOR's multi-rank sweep; the four arrays are malloc'ed, the caller frees them */

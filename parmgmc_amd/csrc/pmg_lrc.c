@@ -275,6 +275,21 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
   return PMG_SUCCESS;
 }
 
+/* The low-rank term of a residual, RESTRICTED: P^T (B S B^T x) = B_c (S B^T x) with B_c = P^T B the block of the next
+   coarser level (src/pc_gamgmc.c:177-178).  lf: the fine level's update (x_fine in ITS layout), lc: the coarse level's
+   (b_coarse in its layout); b_coarse -= B_c (S B_f^T x_fine).  Used behind the fused residual + restriction, which never
+   forms the fine residual; equal to restricting r - B S B^T x up to rounding. */
+pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc lf, pmg_lrc lc, const double *x_fine_lay, double *b_coarse_lay, void *stream)
+{
+  PMG_CHECK(lf && lc && lf->k == lc->k, PMG_ERR_ARG_WRONG, "low-rank updates of two consecutive levels expected");
+  PMG_CHECK(!lf->reduce && !lc->reduce && !lf->empty && !lc->empty, PMG_ERR_SUP, "single-device levels only");
+  if (lf->ns) PMG_KERNEL(pmgk_lrc_btx_rows(lf->ns, lf->k, lf->Bc, lf->rows, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
+  else PMG_KERNEL(pmgk_lrc_btx(lf->ld, lf->k, lf->B, lf->ld, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
+  if (lc->ns) PMG_KERNEL(pmgk_lrc_axpy_rows(lc->ns, lc->k, lc->Bc, lc->rows, lf->wk, -1.0, b_coarse_lay, NULL, stream));
+  else PMG_KERNEL(pmgk_lrc_axpy_cols(lc->ld, lc->k, lc->B, lc->ld, lf->wk, -1.0, b_coarse_lay, b_coarse_lay, stream));
+  return PMG_SUCCESS;
+}
+
 /* y -= Bb_dir (B^T y), src/mc_sor.c:101-112 */
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
 {

@@ -1664,11 +1664,14 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       else PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
     }
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
-    if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev) { /* b_{l-1} = P^T (b - A x) in one pass */
+    if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev && (!pmg_grid_lrc(Lv->g) || (Cc->is_st27 && Cc->lrc))) { /* b_{l-1} = P^T (b - A x) in one pass */
       const pmgk_st27_dims CD = level_dims(Cc);
       int                  done = 0;
       PMG_CALL(pmg_grid_residual_restrict(Lv->g, Lv->b, Lv->x, NULL, NULL, &CD, Cc->b, &done, stream));
-      if (done) continue;
+      if (done) {
+        if (pmg_grid_lrc(Lv->g)) PMG_CALL(pmg_lrc_residual_sub_restricted(pmg_grid_lrc(Lv->g), Cc->lrc, Lv->x, Cc->b, stream)); /* - P^T B S B^T x = - B_{l-1} (S B^T x) */
+        continue;
+      }
     }
     if (Lv->is_grid && Lv->rr_slab && Lv->b == h->b_lay) { /* z-slab, in-place form: b's ghost planes are current */
       PMG_CALL(mg_residual_restrict_slab(h, l, stream));
@@ -1850,7 +1853,7 @@ pmg_status pmg_mgmc_level_residual_restrict(pmg_mgmc h, int32_t level, const dou
   PMG_CALL(level_checked(h, level, 1, &Lv));
   PMG_CHECK(b_lvl && x_lvl && b_coarse, PMG_ERR_ARG_NULL, "null vector");
   int done = 0;
-  if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev) {
+  if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev && !pmg_grid_lrc(Lv->g)) {
     const pmgk_st27_dims CD = level_dims(&h->lv[level - 1]);
     PMG_CALL(pmg_grid_residual_restrict(Lv->g, b_lvl, x_lvl, NULL, NULL, &CD, b_coarse, &done, stream));
   }
