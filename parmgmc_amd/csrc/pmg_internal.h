@@ -58,6 +58,7 @@ pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream); /* after the sweep that us
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream);
 pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc l_fine, pmg_lrc l_coarse, const double *x_fine_lay, double *b_coarse_lay, void *stream);
+int        pmg_lrc_is_local(pmg_lrc l);
 pmg_lrc    pmg_grid_lrc(pmg_grid g); /* the grid operator's low-rank update, NULL if none (borrowed) */
 void       pmg_lrc_destroy(pmg_lrc *l);
 pmg_status pmg_mcsor_set_idiag_by_division(pmg_mcsor mc, int on); /* PCPARSOR's idiag = omega / d */

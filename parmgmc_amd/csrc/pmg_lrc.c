@@ -275,6 +275,9 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
   return PMG_SUCCESS;
 }
 
+/* 1: the update lives on one device (no reduction over ranks, rows on this rank) */
+int pmg_lrc_is_local(pmg_lrc l) { return l && !l->reduce && !l->empty; }
+
 /* The low-rank term of a residual, RESTRICTED: P^T (B S B^T x) = B_c (S B^T x) with B_c = P^T B the block of the next
    coarser level (src/pc_gamgmc.c:177-178).  lf: the fine level's update (x_fine in ITS layout), lc: the coarse level's
    (b_coarse in its layout); b_coarse -= B_c (S B_f^T x_fine).  Used behind the fused residual + restriction, which never

@@ -1664,12 +1664,13 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       else PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
     }
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
-    if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->lrc && !Lv->cpos_dev && (!pmg_grid_lrc(Lv->g) || (Cc->is_st27 && Cc->lrc))) { /* b_{l-1} = P^T (b - A x) in one pass */
+    pmg_lrc flrc = Lv->is_grid ? (Lv->lrc ? Lv->lrc : pmg_grid_lrc(Lv->g)) : NULL; /* the grid level's low-rank update (held by the level on a slab hierarchy, by the grid object otherwise) */
+    if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->cpos_dev && (!flrc || (pmg_lrc_is_local(flrc) && Cc->is_st27 && pmg_lrc_is_local(Cc->lrc)))) { /* b_{l-1} = P^T (b - A x) in one pass */
       const pmgk_st27_dims CD = level_dims(Cc);
       int                  done = 0;
       PMG_CALL(pmg_grid_residual_restrict(Lv->g, Lv->b, Lv->x, NULL, NULL, &CD, Cc->b, &done, stream));
       if (done) {
-        if (pmg_grid_lrc(Lv->g)) PMG_CALL(pmg_lrc_residual_sub_restricted(pmg_grid_lrc(Lv->g), Cc->lrc, Lv->x, Cc->b, stream)); /* - P^T B S B^T x = - B_{l-1} (S B^T x) */
+        if (flrc) PMG_CALL(pmg_lrc_residual_sub_restricted(flrc, Cc->lrc, Lv->x, Cc->b, stream)); /* - P^T B S B^T x = - B_{l-1} (S B^T x) */
         continue;
       }
     }
