@@ -285,9 +285,12 @@ int pmg_lrc_is_local(pmg_lrc l) { return l && !l->reduce && !l->empty; }
 pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc lf, pmg_lrc lc, const double *x_fine_lay, double *b_coarse_lay, void *stream)
 {
   PMG_CHECK(lf && lc && lf->k == lc->k, PMG_ERR_ARG_WRONG, "low-rank updates of two consecutive levels expected");
-  PMG_CHECK(!lf->reduce && !lc->reduce && !lf->empty && !lc->empty, PMG_ERR_SUP, "single-device levels only");
-  if (lf->ns) PMG_KERNEL(pmgk_lrc_btx_rows(lf->ns, lf->k, lf->Bc, lf->rows, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
+  /* S B_f^T x: per rank over its rows, summed over the ranks of a distributed level (a rank without rows contributes zeros) */
+  if (lf->empty) PMG_HIP(hipMemsetAsync(lf->wk, 0, sizeof(double) * (size_t)lf->k, (hipStream_t)stream));
+  else if (lf->ns) PMG_KERNEL(pmgk_lrc_btx_rows(lf->ns, lf->k, lf->Bc, lf->rows, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
   else PMG_KERNEL(pmgk_lrc_btx(lf->ld, lf->k, lf->B, lf->ld, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
+  if (lf->reduce) PMG_CALL(lf->reduce(lf->rctx, lf->wk, lf->k, stream));
+  if (lc->empty) return PMG_SUCCESS; /* none of B_c's rows on this rank */
   if (lc->ns) PMG_KERNEL(pmgk_lrc_axpy_rows(lc->ns, lc->k, lc->Bc, lc->rows, lf->wk, -1.0, b_coarse_lay, NULL, stream));
   else PMG_KERNEL(pmgk_lrc_axpy_cols(lc->ld, lc->k, lc->B, lc->ld, lf->wk, -1.0, b_coarse_lay, b_coarse_lay, stream));
   return PMG_SUCCESS;

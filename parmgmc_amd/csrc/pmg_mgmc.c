@@ -1424,7 +1424,7 @@ static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
     PMG_HIP(hipMemset(Lv->x, 0, sizeof(double) * (size_t)Lv->ld));
     PMG_HIP(hipMemset(Lv->r, 0, sizeof(double) * (size_t)Lv->ld));
     if (st27_use_pair(Lv) || st27_use_pair_slab(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld)); /* zero-filled: the ghost planes stay zero */
-    if (l >= 1 && Lv->is_grid && Lv->distributed && Lv->grid_transfer && !Lv->cpos_dev && !h->lrc_k && !(getenv("PMG_GRID_FUSED_RR_SLAB") && !atoi(getenv("PMG_GRID_FUSED_RR_SLAB")))) {
+    if (l >= 1 && Lv->is_grid && Lv->distributed && Lv->grid_transfer && !Lv->cpos_dev && (!h->lrc_k || (Lv->lrc && h->lv[l - 1].lrc)) && !(getenv("PMG_GRID_FUSED_RR_SLAB") && !atoi(getenv("PMG_GRID_FUSED_RR_SLAB")))) {
       /* the fused residual + restriction on a z-slab: every rank needs two planes (it hands its second and second-to-last
          ones to the neighbours) and a coarse plane of its own; decided from the cuts, identically on every rank */
       const int32_t *fc = h->cuts + (size_t)l * (size_t)(h->nranks + 1), *cc = h->cuts + (size_t)(l - 1) * (size_t)(h->nranks + 1);
@@ -1615,6 +1615,7 @@ static pmg_status mg_residual_restrict_slab(pmg_mgmc h, int l, void *stream)
   int done = 0;
   PMG_CALL(pmg_grid_residual_restrict(Lv->g, Lv->b, Lv->x, Lv->kz0 > 0 ? Lv->y2lo : NULL, Lv->kz0 + Lv->nzl < Lv->nz ? Lv->y2hi : NULL, &CD, bc, &done, stream));
   PMG_CHECK(done, PMG_ERR_PLIB, "level %d: the fused residual + restriction refused a slab the set-up had accepted", l);
+  if (Lv->lrc) PMG_CALL(pmg_lrc_residual_sub_restricted(Lv->lrc, Cc->lrc, Lv->x, Cc->b, stream)); /* - P^T B S B^T x = - B_{l-1} (S B^T x); B^T x summed over the ranks */
   if (fold) {
     int64_t offs[64], cnts[64];
     PMG_CHECK(h->nranks <= 64, PMG_ERR_ARG_OUTOFRANGE, "too many ranks");
