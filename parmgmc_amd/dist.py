@@ -659,6 +659,70 @@ def rowblock_plan(ci_global, row0: int, row1: int, n_global: int, colors_owned, 
     return ghosts, plan
 
 
+def rowblock_hierarchy(operators, interpolations, colorings, rank: int, world: int, starts=None, replicate_below: int = 50000, group=None):
+    """This rank's share of a hierarchy distributed by row blocks -- host arrays only, no device, no C call; collective
+    (the ghost plans of rowblock_plan).  operators / interpolations as for MGMC.from_hierarchy (level 0 = coarsest),
+    colorings[l] = (colours of ALL rows of level l, number of colours) for the levels that will be row blocks (None below).
+    Returns dict(fold, starts, n, levels): levels[l] for l >= fold holds the local operator (rp, ci, v: owned rows in
+    global order, entries in global CSR order, then one identity row per ghost), colors (owned rows), ncolors, plan,
+    ghosts (sorted global rows), nowned, row0, P (owned rows of P_l, columns in the local numbering of level l-1 -- global
+    when that level is replicated) and R (the rows of P_l^T this rank owns on level l-1, columns in the local numbering of
+    level l, entries by ascending global fine row).  Levels below `fold` are replicated (levels[l] = None)."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    L = len(operators)
+    assert L >= 2 and len(interpolations) == L
+    A = [sp.csr_matrix((np.asarray(v, np.float64), np.asarray(ci, np.int64), np.asarray(rp, np.int64)), shape=(len(rp) - 1, len(rp) - 1)) for rp, ci, v in operators]
+    P = [None] + [sp.csr_matrix((np.asarray(interpolations[l][2], np.float64), np.asarray(interpolations[l][1], np.int64), np.asarray(interpolations[l][0], np.int64)), shape=(A[l].shape[0], A[l - 1].shape[0])) for l in range(1, L)]
+    n = [a.shape[0] for a in A]
+    if starts is None:
+        starts = [np.linspace(0, n[l], world + 1).astype(np.int64) for l in range(L)]
+    starts = [np.asarray(s_, np.int64) for s_ in starts]
+    r0 = [int(s_[rank]) for s_ in starts]
+    r1 = [int(s_[rank + 1]) for s_ in starts]
+    R = [None] + [P[l].T.tocsr() for l in range(1, L)]  # rows of P^T, entries by ascending fine row
+    for m in R[1:]:
+        m.sort_indices()
+    fold = 1  # lowest row-block level; the levels below are replicated
+    while fold < L - 1 and n[fold] <= replicate_below:
+        fold += 1
+    ghosts, nloc = [np.zeros(0, np.int64)] * L, [r1[l] - r0[l] for l in range(L)]
+    local_of = [None] * L  # global row -> local row of this rank (owned, then ghosts), -1 elsewhere; replicated levels: identity
+    for l in range(fold):
+        local_of[l] = np.arange(n[l], dtype=np.int64)
+    levels = [None] * L
+    for l in range(fold, L):
+        col, ncol = colorings[l]
+        col = np.asarray(col)
+        mine = A[l][r0[l]:r1[l]]
+        extra = [R[l][r0[l - 1]:r1[l - 1]].indices.astype(np.int64)]  # fine rows my restriction rows read (level l-1 replicated: the block I restrict into)
+        if l + 1 < L:
+            extra.append(P[l + 1][r0[l + 1]:r1[l + 1]].indices.astype(np.int64))  # rows of this level the finer level's interpolation reads
+        ghosts[l], plan = rowblock_plan(mine.indices, r0[l], r1[l], n[l], col[r0[l]:r1[l]], ncol, np.concatenate(extra), rank, world, group)
+        ng = len(ghosts[l])
+        lo = np.full(n[l], -1, np.int64)
+        lo[r0[l]:r1[l]] = np.arange(nloc[l])
+        lo[ghosts[l]] = nloc[l] + np.arange(ng)
+        local_of[l] = lo
+        # local operator: my rows (entries in the order of the global CSR row) + one identity row per ghost
+        rp = np.concatenate([mine.indptr, mine.indptr[-1] + 1 + np.arange(ng)]).astype(np.int32)
+        ci = np.concatenate([lo[mine.indices], nloc[l] + np.arange(ng)]).astype(np.int32)
+        assert ci.min(initial=0) >= 0
+        v = np.concatenate([mine.data, np.ones(ng)])
+        levels[l] = dict(rp=rp, ci=ci, v=v, colors=np.ascontiguousarray(col[r0[l]:r1[l]], np.int32), ncolors=int(ncol), plan=plan, ghosts=ghosts[l], nowned=nloc[l], row0=r0[l])
+    for l in range(fold, L):
+        pm = P[l][r0[l]:r1[l]]  # my rows of P_l (entries in the caller's order), columns -> local numbering of level l-1
+        prp, pci, pv = pm.indptr.astype(np.int32), local_of[l - 1][pm.indices].astype(np.int32), np.ascontiguousarray(pm.data)
+        rm = R[l][r0[l - 1]:r1[l - 1]]  # the rows of P_l^T I own on level l-1, columns -> local numbering of level l
+        rrp, rci, rv = rm.indptr.astype(np.int32), local_of[l][rm.indices].astype(np.int32), np.ascontiguousarray(rm.data)
+        assert pci.min(initial=0) >= 0 and rci.min(initial=0) >= 0, "a transfer reads a row that is neither owned nor a ghost"
+        levels[l]["P"] = (prp, pci, pv)
+        levels[l]["R"] = (rrp, rci, rv)
+        levels[l]["ncoarse_local"] = n[l - 1] if l == fold else nloc[l - 1] + len(ghosts[l - 1])
+    return dict(fold=fold, starts=starts, n=n, levels=levels)
+
+
 class DistAIJMGMC:
     """MGMC sampler on a caller-supplied hierarchy of assembled MATAIJ matrices distributed by ROW BLOCKS, one rank per
     device: the reference's PCGAMGMC on a MATMPIAIJ (src/pc_gamgmc.c:157-223; level sampler MCSORApply_MPIAIJ,
@@ -687,14 +751,7 @@ class DistAIJMGMC:
         self.rank, self.world, self.group = rank, world, group
         L = len(operators)
         assert L >= 2 and len(interpolations) == L
-        A = [sp.csr_matrix((np.asarray(v, np.float64), np.asarray(ci, np.int64), np.asarray(rp, np.int64)), shape=(len(rp) - 1, len(rp) - 1)) for rp, ci, v in operators]
-        P = [None] + [sp.csr_matrix((np.asarray(interpolations[l][2], np.float64), np.asarray(interpolations[l][1], np.int64), np.asarray(interpolations[l][0], np.int64)), shape=(A[l].shape[0], A[l - 1].shape[0])) for l in range(1, L)]
-        n = [a.shape[0] for a in A]
-        if starts is None:
-            starts = [np.linspace(0, n[l], world + 1).astype(np.int64) for l in range(L)]
-        self.starts = [np.asarray(s, np.int64) for s in starts]
-        r0 = [int(s[rank]) for s in self.starts]
-        r1 = [int(s[rank + 1]) for s in self.starts]
+        n = [len(op[0]) - 1 for op in operators]
         # --- transport: the generic all-gather of pmg_dist.c ("ipc" peer stores or RCCL), agreed between the ranks
         on_gpu = dist.get_backend(group) == "nccl"
         want_tr = transport or os.environ.get("PMG_DIST_TRANSPORT")
@@ -716,72 +773,49 @@ class DistAIJMGMC:
                 print(f"[parmgmc_amd] transport '{cand}' unavailable for the row-block hierarchy ({err if err else 'on another rank'})", flush=True)
         if self._drv is None:
             raise RuntimeError("DistAIJMGMC needs the 'ipc' or 'rccl' transport of the HIP library")
-        # --- per level: global colouring (the library's first-fit rule, as MGMC.from_hierarchy applies it), ghost sets, plans
-        self._keep = []
+        # --- the global colouring of the row-block levels: the library's first-fit rule, as MGMC.from_hierarchy applies it
+        fold = 1
+        while fold < L - 1 and n[fold] <= replicate_below:
+            fold += 1
+        colorings = [None] * L
+        for l in range(fold, L):
+            rp, ci, v = operators[l]
+            mc = MCSOR(np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(v, np.float64)).setup()
+            colorings[l] = (mc.get_coloring(), mc.get_num_colors())
+            mc.destroy()
+        H = rowblock_hierarchy(operators, interpolations, colorings, rank, world, starts=starts, replicate_below=replicate_below, group=group)
+        assert H["fold"] == fold
+        self.fold, self.starts = fold, H["starts"]
+        # --- hand everything to the C hierarchy
+        self._keep = [H]
         self._h = C.c_void_p()
         check(lib.pmg_mgmc_create_hierarchy(L, C.byref(self._h)))
-        a0 = A[0].tocsr()
+        a0 = sp.csr_matrix((np.asarray(operators[0][2], np.float64), np.asarray(operators[0][1], np.int64), np.asarray(operators[0][0], np.int64)), shape=(n[0], n[0]))
         a0.sort_indices()
         rp0, ci0, v0 = a0.indptr.astype(np.int32), a0.indices.astype(np.int32), np.ascontiguousarray(a0.data)
         self._keep.append((rp0, ci0, v0))
         check(lib.pmg_mgmc_set_level_operator(self._h, 0, n[0], rp0.ctypes.data, ci0.ctypes.data, v0.ctypes.data))
-        R = [None] + [P[l].T.tocsr() for l in range(1, L)]  # rows of P^T, entries by ascending fine row
-        for m in R[1:]:
-            m.sort_indices()
-        fold = 1  # lowest row-block level; the levels below are replicated
-        while fold < L - 1 and n[fold] <= replicate_below:
-            fold += 1
-        self.fold = fold
         cs = np.ascontiguousarray(self.starts[fold - 1], np.int64)  # who restricts which rows of the highest replicated level
         self._keep.append(cs)
         check(lib.pmg_mgmc_set_rowblock_transport(self._h, self._drv._h, cs.ctypes.data))
-        ghosts, nloc = [np.zeros(0, np.int64)] * L, [r1[l] - r0[l] for l in range(L)]
-        local_of = [None] * L  # global row -> local row of this rank (owned, then ghosts), -1 elsewhere; replicated levels: identity
-        for l in range(fold):
-            local_of[l] = np.arange(n[l], dtype=np.int64)
-            if l >= 1:  # replicated level: the whole operator and interpolation, as MGMC.from_hierarchy takes them
-                rp, ci, v = (np.ascontiguousarray(a_, t_) for a_, t_ in zip(operators[l], (np.int32, np.int32, np.float64)))
-                prp, pci, pv = (np.ascontiguousarray(a_, t_) for a_, t_ in zip(interpolations[l], (np.int32, np.int32, np.float64)))
-                self._keep += [rp, ci, v, prp, pci, pv]
-                check(lib.pmg_mgmc_set_level_operator(self._h, l, n[l], rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
-                check(lib.pmg_mgmc_set_level_interpolation(self._h, l, n[l], n[l - 1], prp.ctypes.data, pci.ctypes.data, pv.ctypes.data))
+        for l in range(1, fold):  # replicated level: the whole operator and interpolation, as MGMC.from_hierarchy takes them
+            rp, ci, v = (np.ascontiguousarray(a_, t_) for a_, t_ in zip(operators[l], (np.int32, np.int32, np.float64)))
+            prp, pci, pv = (np.ascontiguousarray(a_, t_) for a_, t_ in zip(interpolations[l], (np.int32, np.int32, np.float64)))
+            self._keep += [rp, ci, v, prp, pci, pv]
+            check(lib.pmg_mgmc_set_level_operator(self._h, l, n[l], rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
+            check(lib.pmg_mgmc_set_level_interpolation(self._h, l, n[l], n[l - 1], prp.ctypes.data, pci.ctypes.data, pv.ctypes.data))
         for l in range(fold, L):
-            Al = A[l]
-            mc = MCSOR(Al.indptr.astype(np.int32), Al.indices.astype(np.int32), Al.data).setup()  # the global colouring, on the device's host code
-            col, ncol = mc.get_coloring(), mc.get_num_colors()
-            mc.destroy()
-            mine = Al[r0[l]:r1[l]]
-            extra = [R[l][r0[l - 1]:r1[l - 1]].indices.astype(np.int64)]  # fine rows my restriction rows read (level l-1 replicated: the block I restrict into)
-            if l + 1 < L:
-                extra.append(P[l + 1][r0[l + 1]:r1[l + 1]].indices.astype(np.int64))  # rows of this level the finer level's interpolation reads
-            ghosts[l], plan = rowblock_plan(mine.indices, r0[l], r1[l], n[l], col[r0[l]:r1[l]], ncol, np.concatenate(extra), rank, world, group)
-            ng = len(ghosts[l])
-            lo = np.full(n[l], -1, np.int64)
-            lo[r0[l]:r1[l]] = np.arange(nloc[l])
-            lo[ghosts[l]] = nloc[l] + np.arange(ng)
-            local_of[l] = lo
-            # local operator: my rows (entries in the order of the global CSR row) + one identity row per ghost
-            rp = np.concatenate([mine.indptr, mine.indptr[-1] + 1 + np.arange(ng)]).astype(np.int32)
-            ci = np.concatenate([lo[mine.indices], nloc[l] + np.arange(ng)]).astype(np.int32)
-            assert ci.min(initial=0) >= 0
-            v = np.concatenate([mine.data, np.ones(ng)])
-            cols = np.ascontiguousarray(col[r0[l]:r1[l]], np.int32)
-            self._keep += [rp, ci, v, cols, plan]
-            check(lib.pmg_mgmc_set_level_operator(self._h, l, nloc[l] + ng, rp.ctypes.data, ci.ctypes.data, v.ctypes.data))
-            check(lib.pmg_mgmc_set_level_rowblock(self._h, l, r0[l], nloc[l], ncol, cols.ctypes.data, plan["send_ptr"].ctypes.data, plan["send_rows"].ctypes.data, plan["counts"].ctypes.data,
+            Lv = H["levels"][l]
+            plan, nl = Lv["plan"], Lv["nowned"] + len(Lv["ghosts"])
+            check(lib.pmg_mgmc_set_level_operator(self._h, l, nl, Lv["rp"].ctypes.data, Lv["ci"].ctypes.data, Lv["v"].ctypes.data))
+            check(lib.pmg_mgmc_set_level_rowblock(self._h, l, Lv["row0"], Lv["nowned"], Lv["ncolors"], Lv["colors"].ctypes.data, plan["send_ptr"].ctypes.data, plan["send_rows"].ctypes.data, plan["counts"].ctypes.data,
                                                   plan["recv_ptr"].ctypes.data, plan["recv_src"].ctypes.data, plan["recv_rows"].ctypes.data))
-        for l in range(fold, L):
-            pm = P[l][r0[l]:r1[l]]  # my rows of P_l (entries in the caller's order), columns -> local numbering of level l-1
-            prp, pci, pv = pm.indptr.astype(np.int32), local_of[l - 1][pm.indices].astype(np.int32), np.ascontiguousarray(pm.data)
-            rm = R[l][r0[l - 1]:r1[l - 1]]  # the rows of P_l^T I own on level l-1, columns -> local numbering of level l
-            rrp, rci, rv = rm.indptr.astype(np.int32), local_of[l][rm.indices].astype(np.int32), np.ascontiguousarray(rm.data)
-            assert pci.min(initial=0) >= 0 and rci.min(initial=0) >= 0, "a transfer reads a row that is neither owned nor a ghost"
-            ncl = n[l - 1] if l == fold else nloc[l - 1] + len(ghosts[l - 1])
-            self._keep += [prp, pci, pv, rrp, rci, rv]
-            check(lib.pmg_mgmc_set_level_interpolation(self._h, l, nloc[l], ncl, prp.ctypes.data, pci.ctypes.data, pv.ctypes.data))
-            check(lib.pmg_mgmc_set_level_restriction(self._h, l, len(rrp) - 1, nloc[l] + len(ghosts[l]), rrp.ctypes.data, rci.ctypes.data, rv.ctypes.data))
-        self.n_owned, self.n_local = nloc[L - 1], nloc[L - 1] + len(ghosts[L - 1])
-        self.row_range = (r0[L - 1], r1[L - 1])
+            (prp, pci, pv), (rrp, rci, rv) = Lv["P"], Lv["R"]
+            check(lib.pmg_mgmc_set_level_interpolation(self._h, l, Lv["nowned"], Lv["ncoarse_local"], prp.ctypes.data, pci.ctypes.data, pv.ctypes.data))
+            check(lib.pmg_mgmc_set_level_restriction(self._h, l, len(rrp) - 1, nl, rrp.ctypes.data, rci.ctypes.data, rv.ctypes.data))
+        top = H["levels"][L - 1]
+        self.n_owned, self.n_local = top["nowned"], top["nowned"] + len(top["ghosts"])
+        self.row_range = (top["row0"], top["row0"] + top["nowned"])
         self.levels = L
 
     def set_smoother(self, scaled: bool, omega: float = 1.0, sweep_type: int = SOR_FORWARD_SWEEP, its: int = 1):
