@@ -356,6 +356,12 @@ pmg_status pmg_mgmc_set_coarse(pmg_mgmc mg, int type, int32_t its);
    with the same noise, so both are the same chain up to rounding; the in-place form saves one fine residual, one
    axpy and one memset per sample. */
 pmg_status pmg_mgmc_set_correction_form(pmg_mgmc mg, int literal);
+/* on = 0: residual r = b - A x and restriction b_c = P^T r as two kernels on every level, a MATLRC term subtracted from r
+   BEFORE the restriction: the reference's operation order (PCMG residual on the MATLRC level operator, src/pc_gamgmc.c:194,
+   then MatRestrict).  Default (1): grid levels run ONE kernel that never stores r, and a MATLRC term is subtracted in
+   restricted form, b_c -= B_{l-1} (S B_l^T x) with B_{l-1} = P^T B_l (src/pc_gamgmc.c:177-178) -- equal up to rounding
+   (1e-12 on a whole sample, tests/test_gpu_benchsize_lowrank.py).  Single-device hierarchies: any time; z-slabs: before set-up. */
+pmg_status pmg_mgmc_set_fused_transfers(pmg_mgmc mg, int on);
 /* MATLRC fine operator A + B S B^T (examples/ex4.c): PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:157-196) gives every
    level the operator A_l + B_l S B_l^T, B_{l-1} = P_l^T B_l, for its sampler and its residual; the coarse Cholesky
    sampler factors the explicit sum (src/pc_chols.c:119-153).  B: n_fine x k column-major in the finest level's
@@ -389,6 +395,14 @@ pmg_status pmg_mgmc_level_restrict(pmg_mgmc mg, int32_t level, double *r_fine_lv
    level_residual + level_restrict); PMG_ERR_SUP on levels where the cycle runs the two steps */
 pmg_status pmg_mgmc_level_residual_restrict(pmg_mgmc mg, int32_t level, const double *b_lvl, const double *x_lvl, double *b_coarse_lvl, void *stream);
 pmg_status pmg_mgmc_level_prolong_add(pmg_mgmc mg, int32_t level, const double *e_coarse_lvl, double *x_fine_lvl, void *stream);
+/* the MATLRC update of a level as its kernels hold it (row-compact form: ball observations touch << N rows, src/obs.c:39-50):
+   ns layout positions of the support rows, ascending, and the ns x k column-major blocks of B_l (= P^T ... P^T B,
+   src/pc_gamgmc.c:177-178), Bb forward and Bb backward (MCSORBuildLRCCorrection, src/mc_sor.c:480-544).  NULL arrays query k, ns. */
+pmg_status pmg_mgmc_level_lowrank_factors(pmg_mgmc mg, int32_t level, int32_t *k, int64_t *ns, int64_t *rows_host, double *B_host, double *Bb_fwd_host, double *Bb_bwd_host);
+/* y -= Bb (B^T y), MCSORPostSOR_LRC (src/mc_sor.c:101-112), on a vector in the level's layout */
+pmg_status pmg_mgmc_level_lowrank_post(pmg_mgmc mg, int32_t level, int backward, double *y_lvl, void *stream);
+/* restricted = 0: out (level layout) -= B_l (S B_l^T x); 1: out (layout of level-1) -= B_{l-1} (S B_l^T x) */
+pmg_status pmg_mgmc_level_lowrank_residual_sub(pmg_mgmc mg, int32_t level, int restricted, const double *x_lvl, double *out_lvl, void *stream);
 pmg_status pmg_mgmc_destroy(pmg_mgmc *mg);
 
 /* ------------------------------------------------------------------------------------------------------ */

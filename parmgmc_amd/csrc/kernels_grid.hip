@@ -719,20 +719,30 @@ extern "C" int pmgk_grid_residual(const pmgk_grid_layout *L, const pmgk_grid_op 
 // or permuted coarse levels, even extents.  A z-slab (L->kz0, L->nz; C: the coarse planes it owns) passes y's planes
 // kz0 - 2 and kz0 + nz + 1 in ylo2 / yhi2 (colour 0 plane, then colour 1 plane; NULL at a domain face) and needs b and y
 // current on the ghost planes; a single device passes NULL.
+// 1 where the fused residual + restriction applies to this (slab of a) grid level and its coarse level C; a pure function of
+// the two layouts and of which of the planes kz0 - 2 / kz0 + nz + 1 the caller can supply -- the set-up of a distributed
+// hierarchy evaluates it on every rank and agrees on the result before any rank relies on it
+extern "C" int pmgk_grid_residual_restrict_applies(const pmgk_grid_layout *L, const pmgk_st27_dims *C, int have_lo2, int have_hi2)
+{
+  static const int off  = getenv("PMG_GRID_FUSED_RR") ? !atoi(getenv("PMG_GRID_FUSED_RR")) : 0;
+  const int        tplE = grid_threads_per_line(L);
+  const bool       slab = L->kz0 != 0 || L->nz != L->nzg;
+  if (off || C->nz <= 0) return 0;
+  if (!slab && (C->kz0 != 0 || C->nz != C->nzg)) return 0;
+  if (slab && ((L->kz0 > 0 && !have_lo2) || (L->kz0 + L->nz < L->nzg && !have_hi2) || L->nz < 2)) return 0;
+  if (L->nx < 3 || L->ny < 3 || L->nzg < 3 || !(L->nx & 1) || !(L->ny & 1) || !(L->nzg & 1)) return 0;
+  if (C->nx != (L->nx + 1) / 2 || C->ny != (L->ny + 1) / 2 || C->nzg != (L->nzg + 1) / 2) return 0;
+  if (tplE != (C->nx + 1) / 2 || (int64_t)C->ny * tplE >= ((int64_t)1 << 30)) return 0;
+  if (2 * (int64_t)L->cs * 8 >= ((int64_t)1 << 32)) return 0; // 32-bit byte offsets inside a vector
+  if (slab && (2 * C->kz0 < L->kz0 || 2 * (C->kz0 + C->nz - 1) >= L->kz0 + L->nz)) return 0; // a coarse plane belongs to the owner of its fine plane
+  return 1;
+}
+
 extern "C" int pmgk_grid_residual_restrict(const pmgk_grid_layout *L, const pmgk_grid_op *op, const pmgk_st27_dims *C, const double *b, const double *y, const double *ylo2, const double *yhi2, double *bc, void *stream)
 {
-  static const int off    = getenv("PMG_GRID_FUSED_RR") ? !atoi(getenv("PMG_GRID_FUSED_RR")) : 0;
   static const int kc_env = getenv("PMG_GRID_RR_CHUNK") ? atoi(getenv("PMG_GRID_RR_CHUNK")) : 0;
-  const int        tplE   = grid_threads_per_line(L);
-  const bool       slab   = L->kz0 != 0 || L->nz != L->nzg;
-  if (off || C->nz <= 0) return -1;
-  if (!slab && (C->kz0 != 0 || C->nz != C->nzg)) return -1;
-  if (slab && ((L->kz0 > 0 && !ylo2) || (L->kz0 + L->nz < L->nzg && !yhi2) || L->nz < 2)) return -1;
-  if (L->nx < 3 || L->ny < 3 || L->nzg < 3 || !(L->nx & 1) || !(L->ny & 1) || !(L->nzg & 1)) return -1;
-  if (C->nx != (L->nx + 1) / 2 || C->ny != (L->ny + 1) / 2 || C->nzg != (L->nzg + 1) / 2) return -1;
-  if (tplE != (C->nx + 1) / 2 || (int64_t)C->ny * tplE >= ((int64_t)1 << 30)) return -1;
-  if (2 * (int64_t)L->cs * 8 >= ((int64_t)1 << 32)) return -1; // 32-bit byte offsets inside a vector
-  if (slab && (2 * C->kz0 < L->kz0 || 2 * (C->kz0 + C->nz - 1) >= L->kz0 + L->nz)) return -1; // a coarse plane belongs to the owner of its fine plane
+  if (!pmgk_grid_residual_restrict_applies(L, C, ylo2 != nullptr, yhi2 != nullptr)) return -1;
+  const int     tplE = grid_threads_per_line(L);
   const int     wpp = (int)(((int64_t)C->ny * tplE + 61) / 62);
   int           kc  = kc_env > 0 ? kc_env : 8; // coarse planes per chunk: each chunk re-reads one fine plane
   while (kc_env <= 0 && kc > 2 && (int64_t)wpp * ((C->nz + kc - 1) / kc) < 2048) kc >>= 1;

@@ -342,6 +342,12 @@ pmg_status pmg_grid_residual_restrict(pmg_grid g, const double *b, const double 
   return PMG_SUCCESS;
 }
 
+/* would pmg_grid_residual_restrict run its kernel for this slab and coarse level? (no launch) */
+int pmg_grid_residual_restrict_applies(pmg_grid g, const pmgk_st27_dims *C, int have_lo2, int have_hi2)
+{
+  return g && C ? pmgk_grid_residual_restrict_applies(&g->L, C, have_lo2, have_hi2) : 0;
+}
+
 static pmg_status pmg_grid_scratch(pmg_grid g)
 {
   if (!g->b_cv) PMG_CALL(pmg_dev_alloc((void **)&g->b_cv, sizeof(double) * (size_t)(2 * g->L.cs)));

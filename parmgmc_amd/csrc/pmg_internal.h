@@ -44,6 +44,7 @@ pmg_status pmg_grid_sweep_color_faces_cvec(pmg_grid g, int color, int noisy, int
 /* kernel-side description of a grid object (internal) */
 pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L);
 /* residual and Q1 restriction fused; *done = 0 when the fused kernel does not apply (the caller runs the two steps) */
+int        pmg_grid_residual_restrict_applies(pmg_grid g, const pmgk_st27_dims *C, int have_lo2, int have_hi2);
 pmg_status pmg_grid_residual_restrict(pmg_grid g, const double *b, const double *y, const double *ylo2, const double *yhi2, const pmgk_st27_dims *C, double *b_coarse, int *done, void *stream);
 
 #define PMG_XCH_MAXSEG 4
@@ -59,6 +60,7 @@ pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream);
 pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc l_fine, pmg_lrc l_coarse, const double *x_fine_lay, double *b_coarse_lay, void *stream);
 int        pmg_lrc_is_local(pmg_lrc l);
+pmg_status pmg_lrc_get_compact(pmg_lrc l, int32_t *k, int64_t *ns, int64_t *rows_host, double *B_host, double *Bbf_host, double *Bbb_host);
 pmg_lrc    pmg_grid_lrc(pmg_grid g); /* the grid operator's low-rank update, NULL if none (borrowed) */
 void       pmg_lrc_destroy(pmg_lrc *l);
 pmg_status pmg_mcsor_set_idiag_by_division(pmg_mcsor mc, int on); /* PCPARSOR's idiag = omega / d */

@@ -128,6 +128,7 @@ int pmgk_st27_prolong_add(const pmgk_st27_dims *F, const pmgk_st27_dims *C, int 
    covers the fine local planes kbegin .. kbegin+kcount-1 (-1 and nz are the ghost planes). */
 int pmgk_q1_restrict(const pmgk_grid_layout *L, const pmgk_st27_dims *C, const int32_t *cpos, const double *r_cvec, double *bc, void *stream);
 /* b_coarse = P^T (b - A y) in one launch (same bits as pmgk_grid_residual + pmgk_q1_restrict); -1 = not applicable, nothing launched */
+int pmgk_grid_residual_restrict_applies(const pmgk_grid_layout *L, const pmgk_st27_dims *C, int have_lo2, int have_hi2); /* 1 / 0, launches nothing */
 int pmgk_grid_residual_restrict(const pmgk_grid_layout *L, const pmgk_grid_op *op, const pmgk_st27_dims *C, const double *b_cvec, const double *y_cvec, const double *ylo2, const double *yhi2, double *bc, void *stream);
 int pmgk_q1_prolong_add(const pmgk_grid_layout *L, const pmgk_st27_dims *C, const int32_t *cpos, int kbegin, int kcount, int only_color, const double *ec, double *x_cvec, void *stream);
 /* triangular matrix-vector products of the coarse exact sampler (row-major n x n, lower or upper part) */

@@ -275,6 +275,22 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
   return PMG_SUCCESS;
 }
 
+/* the row-compact factors as the kernels use them (diagnostics): layout positions of the support rows (ascending) and the
+   ns x k column-major blocks of B, Bb forward, Bb backward; NULL arrays query the sizes.  PMG_ERR_SUP for the dense form */
+pmg_status pmg_lrc_get_compact(pmg_lrc l, int32_t *k, int64_t *ns, int64_t *rows_host, double *B_host, double *Bbf_host, double *Bbb_host)
+{
+  PMG_CHECK(l, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(l->ns > 0, PMG_ERR_SUP, "the low-rank factors of this level are kept dense");
+  if (k) *k = l->k;
+  if (ns) *ns = l->ns;
+  const size_t cb = sizeof(double) * (size_t)l->ns * (size_t)l->k;
+  if (rows_host) PMG_HIP(hipMemcpy(rows_host, l->rows, sizeof(int64_t) * (size_t)l->ns, hipMemcpyDeviceToHost));
+  if (B_host) PMG_HIP(hipMemcpy(B_host, l->Bc, cb, hipMemcpyDeviceToHost));
+  if (Bbf_host) PMG_HIP(hipMemcpy(Bbf_host, l->Bbc[0], cb, hipMemcpyDeviceToHost));
+  if (Bbb_host) PMG_HIP(hipMemcpy(Bbb_host, l->Bbc[1], cb, hipMemcpyDeviceToHost));
+  return PMG_SUCCESS;
+}
+
 /* 1: the update lives on one device (no reduction over ranks, rows on this rank) */
 int pmg_lrc_is_local(pmg_lrc l) { return l && !l->reduce && !l->empty; }
 

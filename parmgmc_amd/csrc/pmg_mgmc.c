@@ -81,6 +81,7 @@ struct pmg_mgmc_s {
   int       nu, scaled, sweep_type;
   int       coarse_type, coarse_its; /* 0 = cholsampler, 1 = Gibbs sweeps */
   int       keep_host, is_setup, user_hier;
+  int       no_fused;        /* 1: residual and restriction as two kernels everywhere (pmg_mgmc_set_fused_transfers(mg, 0)) */
   int       correction_form; /* 1: w = b - A y, y += MG(w) literally (src/pc_gamgmc.c:253-256); 0: the same cycle run in place on (b, y) */
   pmg_chol  chol;
   double   *y_lay, *b_lay;
@@ -584,6 +585,17 @@ pmg_status pmg_mgmc_set_correction_form(pmg_mgmc h, int literal)
 {
   PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
   h->correction_form = literal != 0;
+  return PMG_SUCCESS;
+}
+
+/* on = 0: the cycle forms r = b - A x and b_c = P^T r with two kernels on every level, a low-rank term is subtracted
+   from r before the restriction -- the reference's operation order (src/pc_gamgmc.c:194, PCMG's residual then
+   MatRestrict).  Default (1): grid levels fuse the two and subtract a low-rank term in restricted form. */
+pmg_status pmg_mgmc_set_fused_transfers(pmg_mgmc h, int on)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(!h->is_setup || !h->dist, PMG_ERR_ARG_WRONGSTATE, "z-slab hierarchies decide this at set-up");
+  h->no_fused = !on;
   return PMG_SUCCESS;
 }
 
@@ -1424,12 +1436,29 @@ static pmg_status mgmc_setup_stencil(pmg_mgmc h, const st27_table *tab)
     PMG_HIP(hipMemset(Lv->x, 0, sizeof(double) * (size_t)Lv->ld));
     PMG_HIP(hipMemset(Lv->r, 0, sizeof(double) * (size_t)Lv->ld));
     if (st27_use_pair(Lv) || st27_use_pair_slab(Lv)) PMG_CALL(pmg_dev_alloc((void **)&Lv->x2, sizeof(double) * (size_t)Lv->ld)); /* zero-filled: the ghost planes stay zero */
-    if (l >= 1 && Lv->is_grid && Lv->distributed && Lv->grid_transfer && !Lv->cpos_dev && (!h->lrc_k || (Lv->lrc && h->lv[l - 1].lrc)) && !(getenv("PMG_GRID_FUSED_RR_SLAB") && !atoi(getenv("PMG_GRID_FUSED_RR_SLAB")))) {
+    if (l >= 1 && Lv->is_grid && Lv->distributed && Lv->grid_transfer && !Lv->cpos_dev && !h->no_fused && (!h->lrc_k || (Lv->lrc && h->lv[l - 1].lrc)) && !(getenv("PMG_GRID_FUSED_RR_SLAB") && !atoi(getenv("PMG_GRID_FUSED_RR_SLAB")))) {
       /* the fused residual + restriction on a z-slab: every rank needs two planes (it hands its second and second-to-last
-         ones to the neighbours) and a coarse plane of its own; decided from the cuts, identically on every rank */
+         ones to the neighbours) and a coarse plane of its own -- decided from the cuts, identically on every rank -- AND the
+         kernel must accept this rank's own slab (limits that depend on the local layout: slabs differ by a plane).  Every
+         rank dry-runs the kernel's predicate on its slab and the ranks agree with one all-reduce: a rank that would be
+         refused in the cycle (after its peers had entered the next halo) makes all of them keep the two-kernel form */
       const int32_t *fc = h->cuts + (size_t)l * (size_t)(h->nranks + 1), *cc = h->cuts + (size_t)(l - 1) * (size_t)(h->nranks + 1);
       int            ok = 1;
       for (int r = 0; r < h->nranks; ++r) ok = ok && fc[r + 1] - fc[r] >= 2 && cc[r + 1] - cc[r] >= 1;
+      if (ok) {
+        pmgk_st27_dims CD = level_dims(&h->lv[l - 1]);
+        CD.kz0            = cc[h->rank];
+        CD.nz             = cc[h->rank + 1] - cc[h->rank];
+        double  mine      = pmg_grid_residual_restrict_applies(Lv->g, &CD, 1, 1) ? 1.0 : 0.0, all = 0.0;
+        double *flag      = NULL;
+        PMG_CALL(pmg_dev_alloc((void **)&flag, sizeof(double)));
+        pmg_status st = hipMemcpy(flag, &mine, sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? PMG_SUCCESS : pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "upload failed");
+        if (!st) st = pmg_dist_allreduce_sum(h->dist, flag, 1, NULL);
+        if (!st && hipMemcpy(&all, flag, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
+        pmg_dev_free(flag);
+        PMG_CALL(st);
+        ok = all == (double)h->nranks;
+      }
       if (ok) {
         int64_t own, ghost, np;
         PMG_CALL(pmg_grid_halo_plane(Lv->g, 0, 0, &own, &ghost, &np));
@@ -1666,7 +1695,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     }
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
     pmg_lrc flrc = Lv->is_grid ? (Lv->lrc ? Lv->lrc : pmg_grid_lrc(Lv->g)) : NULL; /* the grid level's low-rank update (held by the level on a slab hierarchy, by the grid object otherwise) */
-    if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->cpos_dev && (!flrc || (pmg_lrc_is_local(flrc) && Cc->is_st27 && pmg_lrc_is_local(Cc->lrc)))) { /* b_{l-1} = P^T (b - A x) in one pass */
+    if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->cpos_dev && !h->no_fused && (!flrc || (pmg_lrc_is_local(flrc) && Cc->is_st27 && pmg_lrc_is_local(Cc->lrc)))) { /* b_{l-1} = P^T (b - A x) in one pass */
       const pmgk_st27_dims CD = level_dims(Cc);
       int                  done = 0;
       PMG_CALL(pmg_grid_residual_restrict(Lv->g, Lv->b, Lv->x, NULL, NULL, &CD, Cc->b, &done, stream));
@@ -1869,6 +1898,48 @@ pmg_status pmg_mgmc_level_prolong_add(pmg_mgmc h, int32_t level, const double *e
   PMG_CALL(level_checked(h, level, 1, &Lv));
   PMG_CHECK(e_coarse && x_fine, PMG_ERR_ARG_NULL, "null vector");
   return mg_prolong_add(h, level, e_coarse, x_fine, -1, stream);
+}
+
+/* the MATLRC update of a level (src/pc_gamgmc.c:157-196), single device: held by the grid object on the grid level, by the
+   level on class-stencil levels */
+static pmg_status level_lrc(pmg_mgmc h, int32_t level, int need_coarser, mg_level **Lv, pmg_lrc *l)
+{
+  PMG_CALL(level_checked(h, level, need_coarser, Lv));
+  *l = (*Lv)->is_grid ? ((*Lv)->lrc ? (*Lv)->lrc : pmg_grid_lrc((*Lv)->g)) : (*Lv)->lrc;
+  PMG_CHECK(*l, PMG_ERR_ARG_WRONGSTATE, "level %d carries no low-rank update", level);
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_mgmc_level_lowrank_factors(pmg_mgmc h, int32_t level, int32_t *k, int64_t *ns, int64_t *rows_host, double *B_host, double *Bb_fwd_host, double *Bb_bwd_host)
+{
+  mg_level *Lv;
+  pmg_lrc   l;
+  PMG_CALL(level_lrc(h, level, 0, &Lv, &l));
+  return pmg_lrc_get_compact(l, k, ns, rows_host, B_host, Bb_fwd_host, Bb_bwd_host);
+}
+
+/* y -= Bb (B^T y) with the level's factors, MCSORPostSOR_LRC (src/mc_sor.c:101-112) */
+pmg_status pmg_mgmc_level_lowrank_post(pmg_mgmc h, int32_t level, int backward, double *y_lvl, void *stream)
+{
+  mg_level *Lv;
+  pmg_lrc   l;
+  PMG_CALL(level_lrc(h, level, 0, &Lv, &l));
+  PMG_CHECK(y_lvl, PMG_ERR_ARG_NULL, "null vector");
+  return pmg_lrc_post(l, backward ? PMG_SOR_BACKWARD_SWEEP : PMG_SOR_FORWARD_SWEEP, y_lvl, stream);
+}
+
+/* the low-rank part of the level residual (PCMGSetResidual on the MATLRC operator, src/pc_gamgmc.c:194):
+   restricted = 0: out (this level's layout) -= B_l (S B_l^T x);  restricted = 1: out (the next coarser level's layout)
+   -= B_{l-1} (S B_l^T x), the form the cycle uses behind the fused residual + restriction */
+pmg_status pmg_mgmc_level_lowrank_residual_sub(pmg_mgmc h, int32_t level, int restricted, const double *x_lvl, double *out, void *stream)
+{
+  mg_level *Lv, *Cc;
+  pmg_lrc   l, lc;
+  PMG_CALL(level_lrc(h, level, restricted, &Lv, &l));
+  PMG_CHECK(x_lvl && out, PMG_ERR_ARG_NULL, "null vector");
+  if (!restricted) return pmg_lrc_residual_sub(l, x_lvl, out, stream);
+  PMG_CALL(level_lrc(h, level - 1, 0, &Cc, &lc));
+  return pmg_lrc_residual_sub_restricted(l, lc, x_lvl, out, stream);
 }
 
 pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)

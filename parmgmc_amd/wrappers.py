@@ -308,6 +308,11 @@ class MGMC:
     def set_correction_form(self, literal: bool):
         check(lib.pmg_mgmc_set_correction_form(self._h, int(literal)))
 
+    def set_fused_transfers(self, on: bool):
+        """False: residual and restriction as two kernels, a low-rank term subtracted before the restriction (the
+        reference's operation order); True (default): the fused kernel and the restricted low-rank term."""
+        check(lib.pmg_mgmc_set_fused_transfers(self._h, int(on)))
+
     def set_lowrank(self, B, S):
         """MATLRC fine operator A + B diag(S) B^T, propagated to every level (reference src/pc_gamgmc.c:157-196)."""
         B = np.asfortranarray(B, np.float64)
@@ -362,6 +367,21 @@ class MGMC:
 
     def level_prolong_add(self, level: int, e_coarse, x_fine):
         check(lib.pmg_mgmc_level_prolong_add(self._h, level, _ptr(e_coarse), _ptr(x_fine), _stream()))
+
+    def level_lowrank_factors(self, level: int):
+        """(rows, B, Bb_fwd, Bb_bwd): layout positions of the support rows and the ns x k blocks the kernels use"""
+        k, ns = C.c_int32(), C.c_int64()
+        check(lib.pmg_mgmc_level_lowrank_factors(self._h, level, C.byref(k), C.byref(ns), None, None, None, None))
+        rows = np.zeros(ns.value, np.int64)
+        B, Bf, Bb = (np.zeros((ns.value, k.value), order="F") for _ in range(3))
+        check(lib.pmg_mgmc_level_lowrank_factors(self._h, level, C.byref(k), C.byref(ns), rows.ctypes.data, B.ctypes.data, Bf.ctypes.data, Bb.ctypes.data))
+        return rows, B, Bf, Bb
+
+    def level_lowrank_post(self, level: int, y, backward: bool = False):
+        check(lib.pmg_mgmc_level_lowrank_post(self._h, level, int(backward), _ptr(y), _stream()))
+
+    def level_lowrank_residual_sub(self, level: int, x, out, restricted: bool = False):
+        check(lib.pmg_mgmc_level_lowrank_residual_sub(self._h, level, int(restricted), _ptr(x), _ptr(out), _stream()))
 
     def sample(self, b, y, its: int, seed: int, counter0: int = 0, guesszero: bool = False, callback=None) -> int:
         out = C.c_uint64()

@@ -1,0 +1,131 @@
+"""Oracle parity at the sizes bench.py times for BASELINE config 4 (unstructured MATAIJ path).
+
+bench.py's `secondary_unstructured` line sweeps the P1 matrix of the reference's data/lshape.msh refined 5 times
+(377 089 rows; 1 505 793 after one more refinement) and runs MGMC on its 5-level aggregation hierarchy.  The parity
+cases of test_gpu_mcsor.py stop at 1 200 rows and 19 slices; here the SAME matrices the bench builds meet the oracle:
+WHOLE vectors, every row (a CPU sweep of 1.5 M rows costs a quarter of a second).
+
+  deterministic MCSORApply (reference src/mc_sor.c:256-289), forward / backward / symmetric   bit-exact
+  one noisy Gibbs sample (src/pc_mcgibbs.c:119-128,155-188)                                    <= 1e-13
+  two MGMC samples on the hierarchy (src/pc_gamgmc.c:242-259)                                   <= 1e-11
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = 0x9E3779B97F4A7C15
+M64 = (1 << 64) - 1
+MESH = Path(__file__).resolve().parent / "golden" / "lshape.msh"
+
+
+def dev(a):
+    import torch
+
+    return torch.as_tensor(np.ascontiguousarray(a, np.float64), device="cuda")
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def level_seed(seed, l):
+    return (seed + GOLD * (l + 1)) & M64
+
+
+_cache = {}
+
+
+def lshape_matrix(refine):
+    """exactly what bench.py's unstructured_secondary builds (bench.py: read, refine, assemble_p1(kappa = 1))"""
+    from parmgmc_amd.unstructured import assemble_p1, read_gmsh41_triangles, refine_uniform
+
+    if refine not in _cache:
+        base = max((r for r in _cache if r < refine), default=None)
+        if base is None:
+            xy, tris = read_gmsh41_triangles(MESH)
+            r0 = 0
+        else:
+            xy, tris, _ = _cache[base]
+            r0 = base
+        for _ in range(refine - r0):
+            xy, tris = refine_uniform(xy, tris)
+        _cache[refine] = (xy, tris, assemble_p1(xy, tris, 1.0))
+    return _cache[refine][2]
+
+
+@pytest.mark.parametrize("refine,rows", [(5, 377089), (6, 1505793)])
+def test_whole_vector_sweeps_at_bench_size(refine, rows):
+    from parmgmc_amd import MCSOR
+
+    As = lshape_matrix(refine)
+    assert As.shape[0] == rows
+    A = O.CSR.from_scipy(As)
+    mc = MCSOR(As.indptr, As.indices, As.data).setup()
+    col = mc.get_coloring()
+    assert np.array_equal(col, O.coloring_greedy(A)) and O.coloring_is_valid(A, col)  # index maps: bit-exact
+    assert mc.get_num_colors() == col.max() + 1 == 6
+    rng = np.random.default_rng(40 + refine)
+    b, y = rng.standard_normal(A.n), rng.standard_normal(A.n)
+    bd = dev(b)
+    for om in (1.0, 1.2):
+        mc.set_omega(om)
+        for t in (O.SOR_FORWARD, O.SOR_BACKWARD, O.SOR_SYMMETRIC):
+            mc.set_sweep_type(t)
+            yd = dev(y)
+            mc.apply(bd, yd)
+            got, want = host(yd), O.mcsor_apply(A, col, b, y, om, t)
+            assert np.array_equal(got, want), (refine, om, t, int((got != want).sum()))
+    # negative control: the comparison sees a single wrong row
+    want[rows // 2] = np.nextafter(want[rows // 2], np.inf)
+    assert not np.array_equal(got, want)
+    # the bench's own call: forward noisy samples, omega = 1, seed 0xCAFE
+    mc.set_omega(1.0)
+    mc.set_sweep_type(O.SOR_FORWARD)
+    yd = dev(y)
+    nxt = mc.sample(bd, yd, 2, seed=0xCAFE, counter0=3, scaled=True)
+    assert nxt == 5
+    want = O.gibbs_samples(A, col, b, y, 2, lambda d: O.noise_rows(A.n, 0xCAFE, 3 + d), 1.0, O.SOR_FORWARD, True)
+    assert np.abs(host(yd) - want).max() / np.abs(want).max() < 1e-13
+
+
+def test_mgmc_on_the_bench_hierarchy():
+    """bench.py: build_hierarchy(A, coarse_max=2000) -> MGMC.from_hierarchy, set_smoother(True, 1.0, 1, 1)"""
+    from parmgmc_amd import MGMC
+    from parmgmc_amd.unstructured import build_hierarchy
+
+    As = lshape_matrix(5)
+    ops, ps = build_hierarchy(As, coarse_max=2000)
+    sizes = [len(o[0]) - 1 for o in ops]
+    assert sizes == [1549, 6033, 23809, 94593, 377089]
+    nl = len(ops)
+    mg = MGMC.from_hierarchy(ops, ps)
+    mg.set_smoother(True, 1.0, 1, 1)
+    mg.setup()
+    n = sizes[-1]
+    rng = np.random.default_rng(9)
+    b, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    yd = dev(y0)
+    mg.sample(dev(b), yd, 2, seed=0xCAFE, counter0=0)
+    mats = [sp.csr_matrix((o[2], o[1], o[0]), shape=(s, s)) for o, s in zip(ops, sizes)]
+    Ps = [None] + [sp.csr_matrix((p[2], p[1], p[0]), shape=(sizes[l], sizes[l - 1])) for l, p in enumerate(ps) if p is not None]
+    csr = [O.CSR.from_scipy(m) for m in mats]
+    lv = [dict(A=mats[l], P=Ps[l]) for l in range(nl)]
+    cols = [O.coloring_greedy(m) for m in csr]
+    Lc = O.potrf_lower(csr[0].dense())
+    y = y0.copy()
+    for s in range(2):
+        ctr = {l: 64 * s for l in range(nl)}
+
+        def noise(l):
+            c = ctr[l]
+            ctr[l] += 1
+            return O.noise_rows(csr[l].n, level_seed(0xCAFE, l), c)
+
+        smooth = lambda l, rhs, x, leg: O.gibbs_samples(csr[l], cols[l], rhs, x, 1, lambda d: noise(l), 1.0, O.SOR_FORWARD, True)
+        y = O.gamgmc_richardson(lv, b, y, 1, False, smooth, lambda rhs: O.chol_sample(Lc, rhs, noise(0)))
+    assert np.abs(host(yd) - y).max() / np.abs(y).max() < 1e-11
