@@ -56,6 +56,31 @@ def measured_traffic(n: int):
     return best
 
 
+def measured_cycle_traffic(key: str):
+    """HBM bytes per SAMPLE of a secondary workload from the committed PMC summary (profiles/*_cycles_summary.json, written
+    by tools/profile_cycles.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/cyclebench.py,
+    read = 2 x FETCH_SIZE on gfx950, summed over every kernel launched between two samples).  None if absent."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*_cycles_summary.json")):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        w = d.get("workloads", {}).get(key)
+        if w and w.get("hbm_bytes_per_sample"):
+            best = (w["hbm_bytes_per_sample"], f.name)
+    return best
+
+
+def cycle_roofline(alg_bytes: float, ms: float, key: str, n_gpus: int = 1, note: str = "") -> dict:
+    """roofline dict of a secondary line: AS-BUILT algorithmic bytes of one sample (pmg_mgmc_get_algorithmic_bytes: every
+    launch of the cycle counted with the operands it must read and write once -- DESIGN.md section 6 lists the per-kernel
+    figures next to SURVEY 8(d)'s) / measured time per sample, against 8 TB/s per GPU"""
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    tr = measured_cycle_traffic(key) if n_gpus == 1 else None
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * n_gpus), "traffic": tr[0] if tr else None, "traffic_source": tr[1] if tr else None, "algorithmic_bytes_per_sample": alg_bytes, "note": note or "as-built algorithmic bytes of one sample (sum over the kernels the cycle launches, each operand once) / time per sample"}
+
+
 def usable_cores() -> int:
     """cores this process may actually use: scheduler affinity, capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -149,7 +174,8 @@ def mgmc_secondary(n: int = 257, levels: int = 5, its: int = 40) -> dict:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / its
-    return {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample (sorgibbs 1+1, cholsampler on {(n - 1) // 2 ** (levels - 1) + 1}^3)", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "setup_s": setup_s, "model_GBps_at_160B_per_unknown": 160 * n ** 3 / ms / 1e6, "finite": bool(torch.isfinite(y).all().item())}
+    alg, per = mg.algorithmic_bytes()
+    return {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample (sorgibbs 1+1, cholsampler on {(n - 1) // 2 ** (levels - 1) + 1}^3)", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "setup_s": setup_s, "roofline": cycle_roofline(alg, ms, f"mgmc_{n}_{levels}"), "algorithmic_bytes_per_unknown": alg / n ** 3, "algorithmic_bytes_per_level": [float(x) for x in per], "finite": bool(torch.isfinite(y).all().item())}
 
 
 def mgmc_lowrank_secondary(rank: int = 0, world: int = 1, transport=None, share: bool = False, n: int = 257, levels: int = 5, k: int = 3, its: int = 20) -> dict:
@@ -195,7 +221,10 @@ def mgmc_lowrank_secondary(rank: int = 0, world: int = 1, transport=None, share:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(fin, op=dist.ReduceOp.MIN)
     ms = float(t.item()) / its * 1e3
-    res = {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample on A + B S B^T, k = {k} ball observations on every level (row-compact B, Bb), cholsampler of the explicit sum on {(n - 1) // 2 ** (levels - 1) + 1}^3, {world} z-slab(s)", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "n_gpus": world, "transport": mg.transport, "setup_s": setup_s, "finite": bool(fin.item() == 1.0)}
+    alg = torch.tensor([mg.algorithmic_bytes()[0]], dtype=torch.float64, device="cpu" if share else "cuda")
+    if world > 1:
+        dist.all_reduce(alg, op=dist.ReduceOp.SUM)
+    res = {"roofline": cycle_roofline(float(alg.item()), ms, f"mgmc_lowrank_{n}_{levels}_k{k}", world, "as-built algorithmic bytes of one sample incl. the low-rank steps on their support rows (all ranks) / time per sample"), "workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample on A + B S B^T, k = {k} ball observations on every level (row-compact B, Bb), cholsampler of the explicit sum on {(n - 1) // 2 ** (levels - 1) + 1}^3, {world} z-slab(s)", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "n_gpus": world, "transport": mg.transport, "setup_s": setup_s, "finite": bool(fin.item() == 1.0)}
     mg.destroy()
     return res
 
@@ -240,7 +269,9 @@ def unstructured_secondary(refine: int = 5, its: int = 50, larger: bool = True) 
     mg.setup()
     y.zero_()
     ms_mg = timed(lambda its_, c0: mg.sample(b, y, its_, seed=0xCAFE, counter0=c0), its)
-    out = {"workload": f"lshape.msh refined {refine}x: P1 kappa^2 M + K, {n} rows, {nnz} nonzeros; aggregation hierarchy {[len(o[0]) - 1 for o in ops]}", "gibbs_sweep": {"value": 1e3 / ms_sweep, "unit": "samples/s", "ms_per_sample": ms_sweep, "colors": ncol, "model_GBps_at_12nnz_plus_40N": (12 * nnz + 40 * n) / ms_sweep / 1e6}, "mgmc": {"value": 1e3 / ms_mg, "unit": "samples/s", "ms_per_sample": ms_mg, "levels": len(ops)}, "host_setup_s": host_s, "finite": bool(torch.isfinite(y).all().item())}
+    alg_mg = mg.algorithmic_bytes()[0]
+    sell_note = "12 nnz + 40 N bytes per sweep (SURVEY 8(d): 8 B value + 4 B column per stored entry; rowptr, row index, idiag, b, y read, y write per row) / time per sweep"
+    out = {"workload": f"lshape.msh refined {refine}x: P1 kappa^2 M + K, {n} rows, {nnz} nonzeros; aggregation hierarchy {[len(o[0]) - 1 for o in ops]}", "gibbs_sweep": {"value": 1e3 / ms_sweep, "unit": "samples/s", "ms_per_sample": ms_sweep, "colors": ncol, "roofline": cycle_roofline(12 * nnz + 40 * n, ms_sweep, f"sell_sweep_{n}", 1, sell_note)}, "mgmc": {"value": 1e3 / ms_mg, "unit": "samples/s", "ms_per_sample": ms_mg, "levels": len(ops), "roofline": cycle_roofline(alg_mg, ms_mg, f"mgmc_aij_{n}")}, "host_setup_s": host_s, "finite": bool(torch.isfinite(y).all().item())}
     if larger:  # the same sweep one refinement further, where it is no longer bound by the latency of its dependent launches
         del mc, mg
         xy, tris = refine_uniform(xy, tris)
@@ -249,7 +280,7 @@ def unstructured_secondary(refine: int = 5, its: int = 50, larger: bool = True) 
         y2 = torch.zeros(A2.shape[0], dtype=torch.float64, device="cuda")
         mc2 = MCSOR(A2.indptr, A2.indices, A2.data).setup()
         ms2 = timed(lambda its_, c0: mc2.sample(b2, y2, its_, seed=0xCAFE, counter0=c0, scaled=True), its)
-        out["gibbs_sweep_refined_once_more"] = {"rows": A2.shape[0], "nonzeros": A2.nnz, "ms_per_sample": ms2, "colors": mc2.get_num_colors(), "model_GBps_at_12nnz_plus_40N": (12 * A2.nnz + 40 * A2.shape[0]) / ms2 / 1e6}
+        out["gibbs_sweep_refined_once_more"] = {"rows": A2.shape[0], "nonzeros": A2.nnz, "ms_per_sample": ms2, "colors": mc2.get_num_colors(), "roofline": cycle_roofline(12 * A2.nnz + 40 * A2.shape[0], ms2, f"sell_sweep_{A2.shape[0]}", 1, sell_note)}
     return out
 
 
@@ -284,7 +315,10 @@ def mgmc_dist_secondary(rank: int, world: int, transport, share: bool, n: int = 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(fin, op=dist.ReduceOp.MIN)
     ms = float(t.item()) / its * 1e3
-    res = {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample (sorgibbs 1+1, cholsampler on {(n - 1) // 2 ** (levels - 1) + 1}^3), {world} z-slab(s), strong scaling", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "n_gpus": world, "transport": mg.transport, "setup_s": setup_s, "model_GBps_at_160B_per_unknown": 160 * n ** 3 / ms / 1e6, "finite": bool(fin.item() == 1.0)}
+    alg = torch.tensor([mg.algorithmic_bytes()[0]], dtype=torch.float64, device="cpu" if share else "cuda")
+    if world > 1:
+        dist.all_reduce(alg, op=dist.ReduceOp.SUM)  # every rank's share (replicated levels count once per rank: they run on every rank)
+    res = {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample (sorgibbs 1+1, cholsampler on {(n - 1) // 2 ** (levels - 1) + 1}^3), {world} z-slab(s), strong scaling", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "n_gpus": world, "transport": mg.transport, "setup_s": setup_s, "roofline": cycle_roofline(float(alg.item()), ms, f"mgmc_{n}_{levels}", world), "algorithmic_bytes_per_unknown": float(alg.item()) / n ** 3, "finite": bool(fin.item() == 1.0)}
     mg.destroy()
     return res
 
@@ -324,7 +358,9 @@ def unstructured_dist_secondary(rank: int, world: int, transport, share: bool, r
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(fin, op=dist.ReduceOp.MIN)
     ms = float(t.item()) / its * 1e3
-    res = {"workload": f"lshape.msh refined {refine}x: {len(ops[-1][0]) - 1} rows, aggregation hierarchy {[len(o[0]) - 1 for o in ops]}, row blocks over {world} ranks, strong scaling", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "n_gpus": world, "transport": mg.transport, "setup_s": setup_s, "finite": bool(fin.item() == 1.0)}
+    alg = torch.tensor([mg.algorithmic_bytes()[0]], dtype=torch.float64, device=dev)
+    dist.all_reduce(alg, op=dist.ReduceOp.SUM)
+    res = {"roofline": cycle_roofline(float(alg.item()), ms, "", world), "workload": f"lshape.msh refined {refine}x: {len(ops[-1][0]) - 1} rows, aggregation hierarchy {[len(o[0]) - 1 for o in ops]}, row blocks over {world} ranks, strong scaling", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "n_gpus": world, "transport": mg.transport, "setup_s": setup_s, "finite": bool(fin.item() == 1.0)}
     mg.destroy()
     return res
 

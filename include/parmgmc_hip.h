@@ -380,6 +380,12 @@ pmg_status pmg_mgmc_get_level_matrix(pmg_mgmc mg, int32_t level, int which, int3
    y = MG(b) when guesszero != 0), natural-order device vectors.  Sample s = counter0 + it draws its noise from
    counters [64 s, 64 s + 64) of per-level streams, so a chain can be resumed at any sample. */
 pmg_status pmg_mgmc_sample(pmg_mgmc mg, const double *b_nat_dev, double *y_nat_dev, int32_t its, int guesszero, uint64_t seed, uint64_t counter0, uint64_t *counter_out, pmg_sample_callback cb, void *cbctx, void *stream);
+/* ALGORITHMIC bytes of one sample of pmg_mgmc_sample as the cycle is built for this hierarchy (this rank's share): each
+   launch counted with the operands it must read and write once -- SURVEY 8(d)'s per-unit figures (24 B/unknown per
+   structured sweep, 12 nnz + 40 N per sliced-ELL sweep) and their analogues for residual, transfers, coarse sample and
+   low-rank steps, listed at the definition (pmg_mgmc.c) and in DESIGN.md section 6.  per_level_host: nlevels doubles or NULL.
+   What bench.py divides by the measured time per sample for the roofline fraction of its V-cycle lines. */
+pmg_status pmg_mgmc_get_algorithmic_bytes(pmg_mgmc mg, double *total, double *per_level_host);
 /* Diagnostics: ONE kernel of the V-cycle on caller-supplied device vectors in the level's own layout (single device).
    They exist for the parity tests at 257^3 / 513^3, where a whole oracle cycle is out of reach: the tests run one
    kernel and compare sampled rows with the oracle's row arithmetic (PCMG pieces entered at reference

@@ -157,6 +157,7 @@ _sig = {
     "pmg_mgmc_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_mgmc_set_correction_form": (_int, [_vp, _int]),
     "pmg_mgmc_set_fused_transfers": (_int, [_vp, _int]),
+    "pmg_mgmc_get_algorithmic_bytes": (_int, [_vp, C.POINTER(_dbl), _vp]),
     "pmg_mgmc_level_lowrank_factors": (_int, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "pmg_mgmc_level_lowrank_post": (_int, [_vp, _i32, _int, _vp, _vp]),
     "pmg_mgmc_level_lowrank_residual_sub": (_int, [_vp, _i32, _int, _vp, _vp, _vp]),

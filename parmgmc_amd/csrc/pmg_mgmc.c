@@ -72,6 +72,7 @@ typedef struct {
   int64_t      *rb_send_ptr, *rb_recv_ptr, *rb_counts;
   hcsr          R_user; /* rows of the restriction INTO the next coarser level that this rank owns there (borrowed) */
   pmg_distmcsor dm;
+  int64_t       A_nnz, P_nnz; /* stored entries of a sliced-ELL level's operator / of its CSR interpolation (traffic accounting) */
 } mg_level;
 
 struct pmg_mgmc_s {
@@ -821,6 +822,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     PMG_CHECK(pos[l], PMG_ERR_MEM, "out of host memory");
     if (l > 0 || h->coarse_type == 1) {
       PMG_CALL(pmg_mcsor_create_csr(Lv->n, Lv->A_user.rp, Lv->A_user.ci, Lv->A_user.v, &Lv->mc));
+      Lv->A_nnz = Lv->A_user.rp[Lv->n];
       if (Lv->rb) { /* the caller's global colouring on the owned rows, the ghost rows in a colour of their own that is never swept */
         PMG_CHECK(Lv->rb_nowned <= Lv->n, PMG_ERR_ARG_SIZ, "level %d: %d owned rows of %d local rows", l, Lv->rb_nowned, Lv->n);
         int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)Lv->n);
@@ -891,6 +893,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     U->P_nrows = U->P_user.nr;
     U->R_nrows = U->rb ? U->R_user.nr : R.nr;
     PMG_CALL(upload_transfer(&U->P_user, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
+    U->P_nnz = U->P_user.rp[U->P_user.nr];
     if (!U->rb) PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
     else /* the caller's rows of P^T: owned rows of level l-1 (on the replicated coarsest level: this rank's block of the global rows) */
       PMG_CALL(upload_transfer(&U->R_user, pos[l - 1] + (l == h->rb_fold ? h->rb_c0_starts[h->rank] : 0), pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
@@ -1050,6 +1053,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
         for (int32_t j = 0; j < Cc->ny; ++j)
           for (int32_t i = 0; i < Cc->nx; ++i) col[i + Cc->nx * (j + Cc->ny * k)] = remap[(i & 1) + 2 * (j & 1) + 4 * (k & 1)];
       PMG_CALL(pmg_mcsor_create_csr(Cc->n, Ac.rp, Ac.ci, Ac.v, &Cc->mc));
+      Cc->A_nnz = Ac.rp[Cc->n];
       PMG_CALL(pmg_mcsor_set_coloring(Cc->mc, PMG_COLORING_USER, col));
       PMG_CALL(pmg_mcsor_set_omega(Cc->mc, h->omega));
       PMG_CALL(pmg_mcsor_set_sweep_type(Cc->mc, h->sweep_type));
@@ -1082,6 +1086,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
       U->P_nrows = P.nr;
       U->R_nrows = R.nr;
       PMG_CALL(upload_transfer(&P, pos[l], pos[l - 1], &U->P_rowpos, &U->P_rowptr, &U->P_col, &U->P_val));
+      U->P_nnz = P.rp[P.nr];
       PMG_CALL(upload_transfer(&R, pos[l - 1], pos[l], &U->R_rowpos, &U->R_rowptr, &U->R_col, &U->R_val));
     }
     hcsr_free(&R);
@@ -1739,6 +1744,75 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     const int only  = (h->omega == 1.0 && h->nu >= 1 && !no_skip) ? 1 - first : -1;
     PMG_CALL(mg_prolong_add(h, l, h->lv[l - 1].x, Lv->x, only, stream));
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
+  }
+  return PMG_SUCCESS;
+}
+
+/* ALGORITHMIC bytes of ONE sample as the cycle above is built (what bench.py's V-cycle lines divide by their time):
+   every launch of mg_vcycle / pmg_mgmc_sample counted with the operands it must read and write once, per level --
+   this rank's owned unknowns N_l; halos, memsets of skipped zero fills and cache re-reads are NOT counted.
+     grid sweep (matrix-free 7-point)     24 N per directional sweep (32 N at omega != 1): read y, b, write y
+     class-stencil sweep (27 x 27 table)  24 N; 16 N for the zero-guess pre-sweep of the out-of-place kernel (x not read)
+     sliced-ELL sweep                     12 nnz + 40 N
+     zero fill of a level iterate         8 N (skipped where the zero-guess sweep applies)
+     grid residual + restriction fused    16 N + 8 N_c;  unfused: residual 24 N, restriction 8 N + 8 N_c
+     class-stencil residual, restriction  24 N, 8 N + 8 N_c;  sliced-ELL: 12 nnz + 28 N, 12 nnz_P + 12 N_c + 8 N
+     prolongation                         grid, omega = 1: ONE colour, 8 N + 8 N_c; otherwise 16 N + 8 N_c;
+                                          CSR: 12 nnz_P + 20 N + 8 N_c
+     exact coarse sample                  8 N_0^2 (two triangles) ; Gibbs coarse: its sweeps
+     literal correction form              + outer residual 24 N and update 24 N on the finest level, + its zero fill
+     low-rank update per directional sweep on ns support rows: noise term (8 k + 24) ns, repair (16 k + 24) ns;
+                                          residual term (8 k + 8) ns + (8 k + 16) ns' (ns' = ns unrestricted, coarse rows restricted)
+   per_level (may be NULL): nlevels entries, the smoothing / residual / transfer bytes charged to the level they run on
+   (a transfer is charged to its FINE level). */
+pmg_status pmg_mgmc_get_algorithmic_bytes(pmg_mgmc h, double *total, double *per_level)
+{
+  PMG_CHECK(h && total, PMG_ERR_ARG_NULL, "null argument");
+  PMG_CHECK(h->is_setup, PMG_ERR_ARG_WRONGSTATE, "call pmg_mgmc_setup first");
+  const int    top  = h->nlevels - 1;
+  const int    ndir = h->sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
+  const double nsw  = (double)h->nu * ndir; /* directional sweeps per smoothing leg */
+  *total            = 0.0;
+  for (int l = 0; l <= top; ++l) {
+    const mg_level *Lv = &h->lv[l];
+    const double    N  = Lv->is_grid || Lv->padded ? (double)Lv->nx * Lv->ny * Lv->nzl : (double)(Lv->rb ? Lv->rb_nowned : Lv->n);
+    double          by = 0.0;
+    pmg_lrc         lr = Lv->is_grid ? (Lv->lrc ? Lv->lrc : pmg_grid_lrc(Lv->g)) : Lv->lrc;
+    int32_t         k  = 0;
+    int64_t         ns = 0;
+    if (lr && pmg_lrc_get_compact(lr, &k, &ns, NULL, NULL, NULL, NULL)) { /* dense factors: every row */
+      k  = h->lrc_k;
+      ns = (int64_t)N;
+    }
+    const double sweep = Lv->is_grid ? (h->omega == 1.0 ? 24.0 : 32.0) * N : (Lv->is_st27 ? 24.0 * N : 12.0 * (double)Lv->A_nnz + 40.0 * N);
+    const double lrsw  = lr ? ((8.0 * k + 24.0) + (16.0 * k + 24.0)) * (double)ns : 0.0;
+    if (l == 0) {
+      by = h->coarse_type == 0 ? 8.0 * N * N : 8.0 * N + h->coarse_its * ndir * (sweep + lrsw);
+    } else {
+      const mg_level *Cc = &h->lv[l - 1];
+      const double    Nc = Cc->is_grid || Cc->padded ? (double)Cc->nx * Cc->ny * Cc->nzl : (double)(Cc->rb ? Cc->rb_nowned : Cc->n);
+      const int has_guess = l == top && !h->correction_form;
+      const int unset     = !has_guess && Lv->x2 && st27_use_pair(Lv) && !Lv->lrc && h->nu >= 1; /* zero-guess out-of-place sweep */
+      by += 2.0 * nsw * (sweep + lrsw);
+      if (!has_guess) by += unset ? -8.0 * N : 8.0 * N; /* the first sweep does not read x / the zero fill */
+      const int fused = Lv->is_grid && Lv->grid_transfer && !Lv->cpos_dev && !h->no_fused &&
+                        (Lv->distributed ? Lv->rr_slab && !h->correction_form : (!lr || (pmg_lrc_is_local(lr) && Cc->is_st27 && pmg_lrc_is_local(Cc->lrc))));
+      if (fused) by += 16.0 * N + 8.0 * Nc;
+      else if (Lv->is_grid || Lv->is_st27) by += 24.0 * N + 8.0 * N + 8.0 * Nc;
+      else by += 12.0 * (double)Lv->A_nnz + 28.0 * N + 12.0 * (double)Lv->P_nnz + 12.0 * Nc + 8.0 * N;
+      if (lr) {
+        int32_t kc = 0;
+        int64_t nc = 0;
+        if (fused && Cc->lrc && !pmg_lrc_get_compact(Cc->lrc, &kc, &nc, NULL, NULL, NULL, NULL)) by += (8.0 * k + 8.0) * (double)ns + (8.0 * k + 16.0) * (double)nc;
+        else by += (8.0 * k + 8.0) * (double)ns + (8.0 * k + 16.0) * (double)ns;
+      }
+      const int one_colour = Lv->is_grid && h->omega == 1.0 && h->nu >= 1 && !getenv("PMG_MG_PROLONG_BOTH");
+      if (Lv->grid_transfer || Lv->nat_transfer) by += (one_colour ? 8.0 : 16.0) * N + 8.0 * Nc;
+      else by += 12.0 * (double)Lv->P_nnz + 20.0 * N + 8.0 * Nc;
+      if (l == top && h->correction_form) by += 48.0 * N + (lr ? (8.0 * k + 8.0) * (double)ns + (8.0 * k + 16.0) * (double)ns : 0.0);
+    }
+    if (per_level) per_level[l] = by;
+    *total += by;
   }
   return PMG_SUCCESS;
 }

@@ -116,6 +116,50 @@ def _all_ok(err, group, what: str) -> None:
         raise RuntimeError(f"{what}: {err or 'failed on another rank'}")
 
 
+def _teardown(drv, world: int, group) -> None:
+    """Orderly end of a transport, COLLECTIVE over all ranks of `group` -- entered by every rank whether or not it holds
+    a driver (drv None: its constructor failed on this rank alone): unmap the peers' blocks, barrier, free the own block.
+    A rank that frees a block a peer still has mapped and exports a fresh one at once gets "invalid argument" from
+    hipIpcGetMemHandle; a rank that skipped the barrier would meet its peers in a different collective."""
+    if drv is not None and getattr(drv, "_h", None):
+        drv.disconnect()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dist.barrier(group=group)
+    if drv is not None:
+        drv.free()
+
+
+def _agree_on_driver(candidates, make, rank: int, world: int, group, what: str):
+    """Try the transports in order; every rank must end up on the same one.  make(name) builds a driver (collective
+    internally; may fail on one rank alone, by raising or by reporting `selftest_error`); success is agreed with an
+    all-reduce, and after a failed agreement EVERY rank -- with or without a driver of its own -- runs the same collective
+    tear-down before the next candidate's constructor starts its own collectives.  Returns (driver, name) or (None, None)."""
+    import torch
+    import torch.distributed as dist
+
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    for cand in candidates:
+        drv, err = None, None
+        try:
+            drv = make(cand)
+            err = getattr(drv, "selftest_error", None)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        flag = torch.tensor([0 if err else 1], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            return drv, cand
+        _teardown(drv, world, group)
+        if rank == 0:
+            print(f"[parmgmc_amd] {what}: transport '{cand}' unavailable ({err if err else 'on another rank'}); trying the next one", flush=True)
+    return None, None
+
+
 class RcclSlabDriver:
     """The C sample loop of pmg_dist.c: RCCL send/recv called straight from the host library, comm stream + events,
     no Python in the loop.  The 128-byte ncclUniqueId of rank 0 is broadcast through torch.distributed."""
@@ -166,23 +210,27 @@ class RcclSlabDriver:
 
         check(lib.pmg_dist_check(self._h))
 
-    def destroy(self):
-        """Collective, orderly tear-down: unmap the peers' blocks, barrier, free the own block (a rank that frees a block
-        a peer still has mapped and exports a fresh one at once gets "invalid argument" from hipIpcGetMemHandle)."""
+    def disconnect(self):
+        """local: unmap the peers' receive blocks"""
+        from .capi import lib
+
+        if self._h:
+            lib.pmg_dist_ipc_disconnect(self._h)
+
+    def free(self):
+        """local: free the handle and the own receive block (after every peer has unmapped it)"""
         import ctypes as C
 
         from .capi import lib
 
+        if self._h:
+            lib.pmg_dist_destroy(C.byref(self._h))
+
+    def destroy(self):
+        """Collective, orderly tear-down: unmap the peers' blocks, barrier, free the own block."""
         if not self._h:
             return
-        lib.pmg_dist_ipc_disconnect(self._h)
-        if getattr(self, "_world", 1) > 1:
-            import torch
-            import torch.distributed as dist
-
-            torch.cuda.synchronize()
-            dist.barrier(group=getattr(self, "_group", None))
-        lib.pmg_dist_destroy(C.byref(self._h))
+        _teardown(self, getattr(self, "_world", 1), getattr(self, "_group", None))
 
     def __del__(self):
         try:
@@ -226,7 +274,14 @@ class IpcSlabDriver(RcclSlabDriver):
             check(lib.pmg_dist_ipc_export(self._h, blob))
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
-        _all_ok(err, group, "ipc: allocating / exporting the receive block")
+        def agree(err, what):  # raises on every rank together: all of them tear the half-built transport down in step
+            try:
+                _all_ok(err, group, what)
+            except Exception:
+                _teardown(self, world, group)
+                raise
+
+        agree(err, "ipc: allocating / exporting the receive block")
         blobs = [None] * world
         dist.all_gather_object(blobs, bytes(blob.raw), group=group)
         try:  # local phase: map the neighbours' (all peers') blocks
@@ -239,9 +294,15 @@ class IpcSlabDriver(RcclSlabDriver):
                 check(lib.pmg_dist_ipc_connect_all(self._h, arr))
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
-        _all_ok(err, group, "ipc: opening the peers' memory handles")
+        agree(err, "ipc: opening the peers' memory handles")
         dist.barrier(group=group)
-        self._selftest(rank, world)  # no collective follows inside this constructor: a failure here is agreed on by the caller
+        # the self-test can fail on ONE rank alone and no collective follows inside this constructor: the failure is kept,
+        # not raised, so that the caller (_agree_on_driver) still holds the object for the collective tear-down
+        self.selftest_error = None
+        try:
+            self._selftest(rank, world)
+        except Exception as e:  # noqa: BLE001
+            self.selftest_error = e
 
     def _selftest(self, rank, world):
         """One round trip of a known pattern with both z-neighbours (peer copies into their blocks, flag words, copy
@@ -309,19 +370,9 @@ class DistGridSampler:
             # preference: ipc (peer copies, lowest latency) -> rccl (ncclSend/ncclRecv) -> torch P2P; every rank must
             # take the same path, so success is agreed with an all-reduce after each attempt
             candidates = [want] if want else (["ipc", "rccl"] if on_gpu else [])
-            for cand in candidates:
-                ok, err = 1, None
-                try:
-                    drv = IpcSlabDriver(self.grid, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(self.grid, rank, world, group=group)
-                except Exception as e:
-                    ok, err, drv = 0, e, None
-                flag = torch.tensor([ok], device="cuda" if on_gpu else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                if int(flag.item()) == 1:
-                    self.rccl, self.transport = drv, cand
-                    break
-                if rank == 0:
-                    print(f"[parmgmc_amd] halo transport '{cand}' unavailable ({err if err else 'on another rank'}); trying the next one", flush=True)
+            drv, name = _agree_on_driver(candidates, lambda cand: IpcSlabDriver(self.grid, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(self.grid, rank, world, group=group), rank, world, group, "halo exchange")
+            if drv is not None:
+                self.rccl, self.transport = drv, name
 
     def check(self):
         """after torch.cuda.synchronize(): raises if the halo transport lost a neighbour"""
@@ -467,19 +518,9 @@ class DistMCSOR:
         want_tr = transport or os.environ.get("PMG_DIST_TRANSPORT")
         if world > 1 and want_tr != "torch":
             on_gpu = dist.get_backend(group) == "nccl"
-            for cand in ([want_tr] if want_tr else (["ipc", "rccl"] if on_gpu else [])):
-                ok, err, drv = 1, None, None
-                try:
-                    drv = IpcSlabDriver(None, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(None, rank, world, group=group)
-                except Exception as e:  # noqa: BLE001
-                    ok, err = 0, e
-                flag = torch.tensor([ok], device="cuda" if on_gpu else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                if int(flag.item()) == 1:
-                    self._drv, self.transport = drv, cand
-                    break
-                if rank == 0:
-                    print(f"[parmgmc_amd] transport '{cand}' unavailable for the row-block sampler ({err if err else 'on another rank'})", flush=True)
+            drv, name = _agree_on_driver([want_tr] if want_tr else (["ipc", "rccl"] if on_gpu else []), lambda cand: IpcSlabDriver(None, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(None, rank, world, group=group), rank, world, group, "row-block sampler")
+            if drv is not None:
+                self._drv, self.transport = drv, name
         if self._drv is not None:
             import ctypes as C
 
@@ -755,22 +796,7 @@ class DistAIJMGMC:
         # --- transport: the generic all-gather of pmg_dist.c ("ipc" peer stores or RCCL), agreed between the ranks
         on_gpu = dist.get_backend(group) == "nccl"
         want_tr = transport or os.environ.get("PMG_DIST_TRANSPORT")
-        self._drv, self.transport = None, None
-        for cand in ([want_tr] if want_tr else ["ipc", "rccl"]):
-            ok, err, drv = 1, None, None
-            try:
-                drv = IpcSlabDriver(None, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(None, rank, world, group=group)
-            except Exception as e:  # noqa: BLE001
-                ok, err = 0, e
-            flag = torch.tensor([ok], device="cuda" if on_gpu else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            if int(flag.item()) == 1:
-                self._drv, self.transport = drv, cand
-                break
-            if drv is not None:
-                drv.destroy()
-            if rank == 0:
-                print(f"[parmgmc_amd] transport '{cand}' unavailable for the row-block hierarchy ({err if err else 'on another rank'})", flush=True)
+        self._drv, self.transport = _agree_on_driver([want_tr] if want_tr else ["ipc", "rccl"], lambda cand: IpcSlabDriver(None, rank, world, group=group) if cand == "ipc" else RcclSlabDriver(None, rank, world, group=group), rank, world, group, "row-block hierarchy")
         if self._drv is None:
             raise RuntimeError("DistAIJMGMC needs the 'ipc' or 'rccl' transport of the HIP library")
         # --- the global colouring of the row-block levels: the library's first-fit rule, as MGMC.from_hierarchy applies it
@@ -827,6 +853,18 @@ class DistAIJMGMC:
         from .capi import check, lib
 
         check(lib.pmg_mgmc_set_correction_form(self._h, int(literal)))
+
+    def algorithmic_bytes(self):
+        """(this rank's algorithmic bytes of one sample, per level): pmg_mgmc_get_algorithmic_bytes"""
+        import ctypes as C
+
+        import numpy as np
+
+        from .capi import check, lib
+
+        tot, per = C.c_double(), np.zeros(self.levels)
+        check(lib.pmg_mgmc_get_algorithmic_bytes(self._h, C.byref(tot), per.ctypes.data))
+        return tot.value, per
 
     def set_lowrank(self, B_owned, S):
         """MATLRC fine operator A + B diag(S) B^T, propagated to every level with the hierarchy's own restriction

@@ -368,6 +368,13 @@ class MGMC:
     def level_prolong_add(self, level: int, e_coarse, x_fine):
         check(lib.pmg_mgmc_level_prolong_add(self._h, level, _ptr(e_coarse), _ptr(x_fine), _stream()))
 
+    def algorithmic_bytes(self):
+        """(total, per_level): algorithmic bytes of one sample as the cycle is built (pmg_mgmc_get_algorithmic_bytes)"""
+        tot = C.c_double()
+        per = np.zeros(self.levels)
+        check(lib.pmg_mgmc_get_algorithmic_bytes(self._h, C.byref(tot), per.ctypes.data))
+        return tot.value, per
+
     def level_lowrank_factors(self, level: int):
         """(rows, B, Bb_fwd, Bb_bwd): layout positions of the support rows and the ns x k blocks the kernels use"""
         k, ns = C.c_int32(), C.c_int64()

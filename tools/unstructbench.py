@@ -10,4 +10,4 @@ import bench  # noqa: E402
 
 for r in [int(a) for a in sys.argv[1:]] or [5, 6, 7]:
     d = bench.unstructured_secondary(refine=r, its=30, larger=False)
-    print(json.dumps({"refine": r, "workload": d["workload"][:90], "sweep_ms": d["gibbs_sweep"]["ms_per_sample"], "colors": d["gibbs_sweep"]["colors"], "model_GBps": d["gibbs_sweep"]["model_GBps_at_12nnz_plus_40N"], "mgmc_ms": d["mgmc"]["ms_per_sample"], "host_setup_s": d["host_setup_s"]}), flush=True)
+    print(json.dumps({"refine": r, "workload": d["workload"][:90], "sweep_ms": d["gibbs_sweep"]["ms_per_sample"], "colors": d["gibbs_sweep"]["colors"], "roofline_frac": d["gibbs_sweep"]["roofline"]["frac"], "mgmc_ms": d["mgmc"]["ms_per_sample"], "host_setup_s": d["host_setup_s"]}), flush=True)
