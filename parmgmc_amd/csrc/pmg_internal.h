@@ -44,6 +44,7 @@ pmg_status pmg_grid_sweep_color_faces_cvec(pmg_grid g, int color, int noisy, int
 /* kernel-side description of a grid object (internal) */
 pmg_status pmg_grid_get_kernel_layout(pmg_grid g, pmgk_grid_layout *L);
 /* residual and Q1 restriction fused; *done = 0 when the fused kernel does not apply (the caller runs the two steps) */
+int32_t    pmg_grid_line_stride(int32_t nx, int32_t ny, int32_t nzg); /* doubles per line of a colour array */
 int        pmg_grid_residual_restrict_applies(pmg_grid g, const pmgk_st27_dims *C, int have_lo2, int have_hi2);
 pmg_status pmg_grid_residual_restrict(pmg_grid g, const double *b, const double *y, const double *ylo2, const double *yhi2, const pmgk_st27_dims *C, double *b_coarse, int *done, void *stream);
 
