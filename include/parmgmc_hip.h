@@ -113,6 +113,7 @@ pmg_status pmg_mcsor_residual(pmg_mcsor mc, const double *b_dev, const double *y
    calls (the V-cycle does): no permutation pass per call.  pmg_mcsor_get_layout writes, for every matrix row, its
    position in the layout. */
 pmg_status pmg_mcsor_layout_len(pmg_mcsor mc, int32_t *ld);
+pmg_status pmg_mcsor_get_size(pmg_mcsor mc, int32_t *n); /* rows of the operator */
 pmg_status pmg_mcsor_get_layout(pmg_mcsor mc, int32_t *pos_of_row_host);
 pmg_status pmg_mcsor_to_layout(pmg_mcsor mc, const double *nat_dev, double *lay_dev, void *stream);
 pmg_status pmg_mcsor_from_layout(pmg_mcsor mc, const double *lay_dev, double *nat_dev, void *stream);
@@ -276,6 +277,10 @@ pmg_status pmg_distmcsor_create(pmg_mcsor mc, pmg_dist dist, int32_t ncolors, co
    work between colours.  Collective.  Bit-identical to the single-process chain for any number of ranks. */
 pmg_status pmg_distmcsor_sample_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
 pmg_status pmg_distmcsor_apply_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int sweep_type, void *stream);
+/* the same on NATURAL-order device vectors of this rank's `nowned` owned rows -- what the local part of a Vec of the
+   MATMPIAIJ holds (VecGetArray, src/mc_sor.c:252-255): converted to the layout and back inside.  y: state in, sample out */
+pmg_status pmg_distmcsor_sample(pmg_distmcsor h, int32_t nowned, const double *b_owned_dev, double *y_owned_dev, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream);
+pmg_status pmg_distmcsor_apply(pmg_distmcsor h, int32_t nowned, const double *b_owned_dev, double *y_owned_dev, int sweep_type, void *stream);
 /* MATLRC operator A + B S B^T on row blocks (src/mc_sor.c:572-595 on a MATMPIAIJ base): B_local is nlocal x k column-major
    in the local row numbering (nlocal = rows of the local operator; this rank's `nowned` rows first; ghost entries ignored), S the k diagonal entries of
    Sigma^-1.  Afterwards every directional sweep of pmg_distmcsor_sample_layout / _apply_layout is followed by
@@ -410,6 +415,103 @@ pmg_status pmg_mgmc_level_lowrank_post(pmg_mgmc mg, int32_t level, int backward,
 /* restricted = 0: out (level layout) -= B_l (S B_l^T x); 1: out (layout of level-1) -= B_{l-1} (S B_l^T x) */
 pmg_status pmg_mgmc_level_lowrank_residual_sub(pmg_mgmc mg, int32_t level, int restricted, const double *x_lvl, double *out_lvl, void *stream);
 pmg_status pmg_mgmc_destroy(pmg_mgmc *mg);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Row-block (MATMPIAIJ) set-up in C: what a caller with an MPI communicator needs to reach the multi-GPU   */
+/* samplers -- replaces MatCreateScatters (src/mc_sor.c:152-214), the MATMPIAIJ branch of MCSORSetUp        */
+/* (:553-605) and the distributed half of PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:157-223)                */
+/* ------------------------------------------------------------------------------------------------------ */
+/* The ONE collective the set-up needs from its caller: a byte all-gather of equal-sized blocks over the ranks of the
+   matrix' communicator (recv holds nranks * nbytes, block r from rank r; 0 = success).  A PETSc adapter passes
+     int ag(void *ctx, const void *s, int64_t n, void *r) { return MPI_Allgather(s, (int)n, MPI_BYTE, r, (int)n, MPI_BYTE, *(MPI_Comm *)ctx); }
+   (adapter/hip_petsc_common.h), the Python tests torch.distributed, examples/pmg_bench.c pipes between forked ranks.
+   Every function that takes a pmg_host_comm is COLLECTIVE over its ranks; a failure on one rank fails on all. */
+typedef int (*pmg_allgather_fn)(void *ctx, const void *send, int64_t nbytes, void *recv);
+typedef struct {
+  int32_t          rank, nranks;
+  pmg_allgather_fn allgather; /* may be NULL when nranks == 1 */
+  void            *ctx;
+} pmg_host_comm;
+
+/* (Ad, Ao, garray) of MatMPIAIJGetSeqAIJ (src/mc_sor.c:308) -> this rank's rows with GLOBAL columns.  Ad: nloc x nloc, local
+   columns (global = col + cstart); Ao: compact columns (global = garray[col]); PetscInt arrays of idx_width bits.  order
+   PMG_ROWBLOCK_ORDER_GLOBAL: entries by ascending global column = the row of the sequential matrix (the distributed chain
+   then equals the single-process chain bit for bit); PMG_ROWBLOCK_ORDER_MPIAIJ: diagonal block first, then the off-diagonal
+   block, as MCSORApply_MPIAIJ visits them (src/mc_sor.c:331-333).  rp_out: nloc + 1; ci_out, v_out: nnz(Ad) + nnz(Ao). */
+#define PMG_ROWBLOCK_ORDER_GLOBAL 0
+#define PMG_ROWBLOCK_ORDER_MPIAIJ 1
+pmg_status pmg_rowblock_merge_mpiaij(int32_t nloc, int64_t cstart, const void *ad_rowptr, const void *ad_colidx, const double *ad_vals, const void *ao_rowptr, const void *ao_colidx, const double *ao_vals, const void *garray, int idx_width, int order, int64_t *rp_out, int64_t *ci_out, double *v_out);
+/* The library's first-fit colouring of the GLOBAL matrix (rows ascending, smallest colour no coloured neighbour carries),
+   computed rank after rank: the colouring one process computes.  row_starts[0..nranks] = MatGetOwnershipRanges. */
+pmg_status pmg_rowblock_color_greedy(const pmg_host_comm *comm, const int64_t *row_starts, const int64_t *rowptr, const int64_t *colidx_global, int32_t *colors_owned, int32_t *ncolors);
+/* Ghost rows + per-colour ghost-update plan of one row block: MatCreateScatters (src/mc_sor.c:152-214) de-duplicated per
+   ghost row and laid out for ONE all-gather per colour.  cols: the global column indices of this rank's rows; extra:
+   further rows of other ranks it reads (transfer columns).  Views (pmg_rowblock_plan_get, borrowed): ghosts = sorted global
+   rows (local row nowned + q); send_ptr[ncolors+1] / send_rows = local owned rows this rank contributes per colour (ascending
+   global row); counts[c * nranks + r]; recv_ptr / recv_src / recv_rows = for every ghost row the index of its value in the
+   colour's gather buffer and its local row -- the arguments of pmg_mgmc_set_level_rowblock. */
+typedef struct pmg_rowblock_plan_s *pmg_rowblock_plan;
+pmg_status pmg_rowblock_plan_create(const pmg_host_comm *comm, const int64_t *row_starts, int64_t ncols, const int64_t *cols, int64_t nextra, const int64_t *extra, int32_t ncolors, const int32_t *colors_owned, pmg_rowblock_plan *plan);
+pmg_status pmg_rowblock_plan_get(pmg_rowblock_plan plan, int32_t *nghost, const int64_t **ghosts, const int64_t **send_ptr, const int32_t **send_rows, const int64_t **counts, const int64_t **recv_ptr, const int32_t **recv_src, const int32_t **recv_rows);
+void       pmg_rowblock_plan_destroy(pmg_rowblock_plan *plan);
+/* A whole hierarchy (level 0 = coarsest) whose levels are MATMPIAIJ matrices -- what PCGAMGMC finds inside PCMG / PCGAMG
+   (src/pc_gamgmc.c:165-176): per level this rank's rows of A_l and of P_l with global columns.  pmg_rbh_build (collective)
+   replicates the levels with at most replicate_below rows (at least the coarsest; < 0: 50 000), colours the others (the
+   caller's colouring or first-fit), forms the rows of P^T every rank owns, the ghost plans and the local matrices;
+   pmg_rbh_create_mgmc hands all of it to pmg_mgmc_create_hierarchy / pmg_mgmc_set_level_*: afterwards pmg_mgmc_set_smoother,
+   pmg_mgmc_set_lowrank, pmg_mgmc_setup, pmg_mgmc_sample as on one device.  Keep the handle until pmg_mgmc_setup returned. */
+typedef struct pmg_rbh_s *pmg_rbh;
+typedef struct {
+  int64_t        n_global, row0;
+  const int64_t *starts; /* nranks + 1 */
+  int32_t        replicated, nowned, nlocal, nghost, ncolors, P_nrows, R_nrows, ncoarse_local;
+  const int32_t *rp, *ci, *colors, *P_rp, *P_ci, *R_rp, *R_ci, *send_rows, *recv_src, *recv_rows;
+  const double  *v, *P_v, *R_v;
+  const int64_t *ghosts, *send_ptr, *counts, *recv_ptr;
+} pmg_rbh_level_view;
+pmg_status pmg_rbh_create(const pmg_host_comm *comm, int32_t nlevels, int64_t replicate_below, pmg_rbh *h);
+pmg_status pmg_rbh_set_level_operator(pmg_rbh h, int32_t level, int64_t n_global, int64_t row0, int64_t nloc, const void *rowptr, const void *colidx_global, const double *vals, int idx_width);
+pmg_status pmg_rbh_set_level_interpolation(pmg_rbh h, int32_t level, int64_t nloc_rows, const void *rowptr, const void *colidx_global_coarse, const double *vals, int idx_width);
+pmg_status pmg_rbh_set_level_coloring(pmg_rbh h, int32_t level, int32_t ncolors, const int32_t *colors_owned);
+pmg_status pmg_rbh_build(pmg_rbh h);
+pmg_status pmg_rbh_get_info(pmg_rbh h, int32_t *nlevels, int32_t *fold);
+pmg_status pmg_rbh_get_level(pmg_rbh h, int32_t level, pmg_rbh_level_view *view);
+pmg_status pmg_rbh_create_mgmc(pmg_rbh h, pmg_dist transport, pmg_mgmc *mg);
+void       pmg_rbh_destroy(pmg_rbh *h);
+/* The stand-alone multicolour sampler on a row block (MCSORCreate + MCSORSetUp on a MATMPIAIJ, src/mc_sor.c:553-605): local
+   operator, device set-up with noise keyed on the global row, ghost plan, C sample loop.  colors_owned NULL: first-fit on
+   the global matrix.  Use with pmg_distmcsor_sample_layout / _apply_layout; destroy *distmcsor, then *mc.  Needs a GPU. */
+pmg_status pmg_rowblock_sampler_create(const pmg_host_comm *comm, pmg_dist transport, const int64_t *row_starts, const void *rowptr, const void *colidx_global, const double *vals, int idx_width, int32_t ncolors, const int32_t *colors_owned, double omega, pmg_mcsor *mc, pmg_distmcsor *distmcsor);
+/* The halo / all-gather transports bootstrapped through the caller's all-gather instead of torch.distributed: kind "ipc"
+   (hipIpc peer stores + flag words; the handle blobs travel through comm) or "rccl" (rank 0's ncclUniqueId travels through
+   comm; rccl_path = the librccl.so to dlopen, NULL: default search).  g = this rank's z-slab (pmg_grid_create with kz0 / nz)
+   for the DMDA samplers, NULL for a pure transport (row blocks).  pmg_dist_destroy_comm: unmap, barrier, free. */
+pmg_status pmg_dist_create_comm(const pmg_host_comm *comm, const char *kind, pmg_grid g, const char *rccl_path, pmg_dist *d);
+pmg_status pmg_dist_destroy_comm(const pmg_host_comm *comm, pmg_dist *d);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* The Woodbury term of PCWOODBURY (src/woodbury.c) for ANY sampler and solver, on one device or on rows    */
+/* distributed over the ranks of a pmg_dist (z-slabs and row blocks alike)                                  */
+/* ------------------------------------------------------------------------------------------------------ */
+/* B_host: this rank's n rows of B (k columns, column-major, leading dimension ldb), S_host: the k entries of S = Sigma^-1
+   (MatLRCGetMats, src/woodbury.c:162); dist NULL: one device, else B^T C and every B^T y are summed over its ranks in rank
+   order (MatTransposeMatMult / MatMultTranspose of the reference's dense MPI matrix, :53,:280).
+     set-up (:21-91):  for every column c: pmg_woodbury_column hands out B(:,c) and a zero-filled C(:,c) on the device, the
+                       caller runs ITS solver on them (C(:,c) = solver(B(:,c)), :39-49); pmg_woodbury_finish forms
+                       G = C (S^-1 + B^T C)^-1 (collective, synchronous);
+     sample (:263-289): pmg_woodbury_noisy_rhs (w = b + B (sqrt|S| o xi), xi from (seed, counter), the same on every rank),
+                       the caller's A-sampler on w, pmg_woodbury_correct (y -= G (B^T y), collective).
+   All vectors: natural order over this rank's rows, device memory. */
+typedef struct pmg_woodbury_s *pmg_woodbury;
+pmg_status pmg_woodbury_create(int64_t n, int32_t k, const double *B_host, int64_t ldb, const double *S_host, pmg_dist dist, pmg_woodbury *w);
+pmg_status pmg_woodbury_column(pmg_woodbury w, int32_t c, const double **B_col_dev, double **C_col_dev, void *stream);
+/* C(:,c) <- a solver result held in the caller's own device vector (VecCopy(x, c), :46-48) */
+pmg_status pmg_woodbury_set_c_column(pmg_woodbury w, int32_t c, const double *x_dev, void *stream);
+pmg_status pmg_woodbury_finish(pmg_woodbury w);
+pmg_status pmg_woodbury_noisy_rhs(pmg_woodbury w, const double *b_dev, double *w_dev, uint64_t seed, uint64_t counter, void *stream);
+pmg_status pmg_woodbury_correct(pmg_woodbury w, double *y_dev, void *stream);
+pmg_status pmg_woodbury_get_correction(pmg_woodbury w, double *G_host);
+pmg_status pmg_woodbury_destroy(pmg_woodbury *w);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* VecSetRandomStandardNormal (src/parmgmc.c:70-116) on the counter-based source: entry r gets the (r&1)    */

@@ -226,10 +226,90 @@ _sig = {
     "pmg_pc_shell_set_context": (_int, [_vp, _vp]),
     "pmg_pc_shell_get_context": (_int, [_vp, C.POINTER(_vp)]),
     "pmg_vec_set_random_standard_normal": (_int, [_i64, _vp, _u64, _u64, _vp]),
+    # row-block set-up in C (pmg_rowblock.c); the pmg_host_comm argument is a pointer to HostComm
+    "pmg_rowblock_merge_mpiaij": (_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),
+    "pmg_rowblock_color_greedy": (_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
+    "pmg_rowblock_plan_create": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _vp, C.POINTER(_vp)]),
+    "pmg_rowblock_plan_get": (_int, [_vp, C.POINTER(_i32)] + [C.POINTER(_vp)] * 7),
+    "pmg_rowblock_plan_destroy": (None, [C.POINTER(_vp)]),
+    "pmg_rbh_create": (_int, [_vp, _i32, _i64, C.POINTER(_vp)]),
+    "pmg_rbh_set_level_operator": (_int, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _int]),
+    "pmg_rbh_set_level_interpolation": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _int]),
+    "pmg_rbh_set_level_coloring": (_int, [_vp, _i32, _i32, _vp]),
+    "pmg_rbh_build": (_int, [_vp]),
+    "pmg_rbh_get_info": (_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "pmg_rbh_get_level": (_int, [_vp, _i32, _vp]),
+    "pmg_rbh_create_mgmc": (_int, [_vp, _vp, C.POINTER(_vp)]),
+    "pmg_rbh_destroy": (None, [C.POINTER(_vp)]),
+    "pmg_rowblock_sampler_create": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i32, _vp, _dbl, C.POINTER(_vp), C.POINTER(_vp)]),
+    "pmg_dist_create_comm": (_int, [_vp, C.c_char_p, _vp, C.c_char_p, C.POINTER(_vp)]),
+    "pmg_dist_destroy_comm": (_int, [_vp, C.POINTER(_vp)]),
+    "pmg_mcsor_get_size": (_int, [_vp, C.POINTER(_i32)]),
+    "pmg_distmcsor_sample": (_int, [_vp, _i32, _vp, _vp, _i32, _int, _int, _u64, _u64, C.POINTER(_u64), _vp]),
+    "pmg_distmcsor_apply": (_int, [_vp, _i32, _vp, _vp, _int, _vp]),
+    "pmg_woodbury_create": (_int, [_i64, _i32, _vp, _i64, _vp, _vp, C.POINTER(_vp)]),
+    "pmg_woodbury_column": (_int, [_vp, _i32, C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "pmg_woodbury_set_c_column": (_int, [_vp, _i32, _vp, _vp]),
+    "pmg_woodbury_finish": (_int, [_vp]),
+    "pmg_woodbury_noisy_rhs": (_int, [_vp, _vp, _vp, _u64, _u64, _vp]),
+    "pmg_woodbury_correct": (_int, [_vp, _vp, _vp]),
+    "pmg_woodbury_get_correction": (_int, [_vp, _vp]),
+    "pmg_woodbury_destroy": (_int, [C.POINTER(_vp)]),
 }
 for _name, (_res, _args) in _sig.items():
     _f = getattr(lib, _name)
     _f.restype, _f.argtypes = _res, _args
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class HostComm(C.Structure):
+    """pmg_host_comm: the byte all-gather the C set-up calls back into"""
+
+    _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("allgather", ALLGATHER_FN), ("ctx", C.c_void_p)]
+
+
+class RbhLevelView(C.Structure):
+    """pmg_rbh_level_view"""
+
+    _fields_ = [("n_global", C.c_int64), ("row0", C.c_int64), ("starts", C.POINTER(C.c_int64))] + [(n_, C.c_int32) for n_ in ("replicated", "nowned", "nlocal", "nghost", "ncolors", "P_nrows", "R_nrows", "ncoarse_local")] + [(n_, C.POINTER(C.c_int32)) for n_ in ("rp", "ci", "colors", "P_rp", "P_ci", "R_rp", "R_ci", "send_rows", "recv_src", "recv_rows")] + [(n_, C.POINTER(C.c_double)) for n_ in ("v", "P_v", "R_v")] + [(n_, C.POINTER(C.c_int64)) for n_ in ("ghosts", "send_ptr", "counts", "recv_ptr")]
+
+
+def torch_host_comm(rank: int, world: int, group=None):
+    """A pmg_host_comm whose all-gather is torch.distributed's (byte tensors on the CPU for gloo, staged through the
+    device for nccl).  Returns (HostComm, keep-alive callback object): hold both while the C side may call back."""
+    import numpy as np
+
+    def _ag(_ctx, send, nbytes, recv):
+        try:
+            import torch
+            import torch.distributed as dist
+
+            src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 1),))[: int(nbytes)]
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.from_numpy(src.copy()).to(dev)
+            out = torch.empty(world * int(nbytes), dtype=torch.uint8, device=dev)
+            if nbytes:
+                if dev == "cuda":
+                    dist.all_gather_into_tensor(out, t, group=group)
+                else:
+                    parts = [torch.empty(int(nbytes), dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, t, group=group)
+                    out = torch.cat(parts)
+                dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(world * int(nbytes),))
+                dst[:] = out.cpu().numpy()
+            else:
+                dist.barrier(group=group)
+            return 0
+        except Exception:  # pragma: no cover
+            import traceback
+
+            traceback.print_exc()
+            return 1
+
+    cb = ALLGATHER_FN(_ag)
+    return HostComm(rank, world, cb, None), cb
 
 
 DELETER = C.CFUNCTYPE(C.c_int, C.c_void_p)

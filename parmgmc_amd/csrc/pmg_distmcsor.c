@@ -37,6 +37,9 @@ struct pmg_distmcsor_s {
   int64_t *all_off, *all_cnt, all_tot;
   int32_t *all_src_dev;
   pmg_lrc  lrc; /* MATLRC update A + B S B^T of the distributed operator (pmg_distmcsor_set_lowrank) */
+  /* scratch of the natural-order entry points (pmg_distmcsor_sample / _apply): local vectors (owned rows, then ghosts) and their layout forms */
+  double  *nat_b, *nat_y, *lay_b, *lay_y;
+  int32_t  nlocal, ld;
 };
 
 pmg_status pmg_distmcsor_destroy(pmg_distmcsor *hp)
@@ -56,6 +59,7 @@ pmg_status pmg_distmcsor_destroy(pmg_distmcsor *hp)
   pmg_dev_free(h->recv_src_dev);
   pmg_dev_free(h->recv_pos_dev);
   pmg_dev_free(h->gbuf);
+  pmg_dev_free(h->nat_b), pmg_dev_free(h->nat_y), pmg_dev_free(h->lay_b), pmg_dev_free(h->lay_y);
   free(h);
   *hp = NULL;
   return PMG_SUCCESS;
@@ -303,6 +307,45 @@ pmg_status pmg_distmcsor_refresh_layout(pmg_distmcsor h, double *v_lay, void *st
 pmg_status pmg_distmcsor_sample_layout(pmg_distmcsor h, const double *b_lay, double *y_lay, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
 {
   return distmcsor_sweeps(h, b_lay, y_lay, its, 1, scaled, sweep_type, seed, counter0, counter_out, stream);
+}
+
+/* The same on NATURAL-order vectors of this rank's owned rows (what a Vec of a MATMPIAIJ holds): MCSORApply / the sample
+   loops of src/pc_mcgibbs.c:155-188 for callers that do not keep their vectors in the layout.  nowned = number of owned
+   rows (the first rows of the local operator).  y's owned rows are the chain's state: in and out. */
+static pmg_status distmcsor_natural(pmg_distmcsor h, int32_t nowned, const double *b_owned, double *y_owned, int32_t its, int noisy, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+{
+  PMG_CHECK(h && (nowned == 0 || (b_owned && y_owned)), PMG_ERR_ARG_NULL, "null argument");
+  if (!h->lay_b) {
+    PMG_CALL(pmg_mcsor_layout_len(h->mc, &h->ld));
+    PMG_CALL(pmg_mcsor_get_size(h->mc, &h->nlocal));
+    const size_t nb = sizeof(double) * (size_t)(h->nlocal > 0 ? h->nlocal : 1), lb = sizeof(double) * (size_t)(h->ld > 0 ? h->ld : 1);
+    PMG_CALL(pmg_dev_alloc((void **)&h->nat_b, nb));
+    PMG_CALL(pmg_dev_alloc((void **)&h->nat_y, nb));
+    PMG_CALL(pmg_dev_alloc((void **)&h->lay_b, lb));
+    PMG_CALL(pmg_dev_alloc((void **)&h->lay_y, lb));
+  }
+  PMG_CHECK(nowned >= 0 && nowned <= h->nlocal, PMG_ERR_ARG_OUTOFRANGE, "%d owned rows of %d local rows", nowned, h->nlocal);
+  hipStream_t s = (hipStream_t)stream;
+  if (nowned) {
+    PMG_HIP(hipMemcpyAsync(h->nat_b, b_owned, sizeof(double) * (size_t)nowned, hipMemcpyDeviceToDevice, s));
+    PMG_HIP(hipMemcpyAsync(h->nat_y, y_owned, sizeof(double) * (size_t)nowned, hipMemcpyDeviceToDevice, s));
+  }
+  PMG_CALL(pmg_mcsor_to_layout(h->mc, h->nat_b, h->lay_b, stream));
+  PMG_CALL(pmg_mcsor_to_layout(h->mc, h->nat_y, h->lay_y, stream));
+  PMG_CALL(distmcsor_sweeps(h, h->lay_b, h->lay_y, its, noisy, scaled, sweep_type, seed, counter0, counter_out, stream));
+  PMG_CALL(pmg_mcsor_from_layout(h->mc, h->lay_y, h->nat_y, stream));
+  if (nowned) PMG_HIP(hipMemcpyAsync(y_owned, h->nat_y, sizeof(double) * (size_t)nowned, hipMemcpyDeviceToDevice, s));
+  return PMG_SUCCESS;
+}
+
+pmg_status pmg_distmcsor_sample(pmg_distmcsor h, int32_t nowned, const double *b_owned_dev, double *y_owned_dev, int32_t its, int scaled, int sweep_type, uint64_t seed, uint64_t counter0, uint64_t *counter_out, void *stream)
+{
+  return distmcsor_natural(h, nowned, b_owned_dev, y_owned_dev, its, 1, scaled, sweep_type, seed, counter0, counter_out, stream);
+}
+
+pmg_status pmg_distmcsor_apply(pmg_distmcsor h, int32_t nowned, const double *b_owned_dev, double *y_owned_dev, int sweep_type, void *stream)
+{
+  return distmcsor_natural(h, nowned, b_owned_dev, y_owned_dev, 1, 0, 0, sweep_type, 0, 0, NULL, stream);
 }
 
 /* MCSORApply: one deterministic sweep of the given type */

@@ -80,4 +80,8 @@ pmg_status pmg_dev_alloc(void **p, size_t bytes);
 pmg_status pmg_dev_upload(void **p, const void *host, size_t bytes);
 void       pmg_dev_free(void *p);
 
+
+/* pmg_rowblock.c */
+void pmg_mcsor_adopt_arrays(pmg_mcsor mc, int32_t *rowptr, int32_t *colidx, double *vals);
+
 #endif

@@ -16,6 +16,7 @@ struct pmg_mcsor_s {
   const int32_t *rowptr, *colidx;
   const double  *vals;
   int32_t       *rowptr_own, *colidx_own; /* 32-bit copies of a 64-bit PetscInt matrix (pmg_mcsor_create_csr_idx) */
+  double        *vals_own;                /* arrays handed over by pmg_mcsor_adopt_arrays */
   /* options */
   double   omega;
   int      omega_changed;
@@ -510,6 +511,14 @@ pmg_status pmg_mcsor_layout_len(pmg_mcsor mc, int32_t *ld)
   return PMG_SUCCESS;
 }
 
+/* number of rows of the operator */
+pmg_status pmg_mcsor_get_size(pmg_mcsor mc, int32_t *n)
+{
+  PMG_CHECK(mc && n, PMG_ERR_ARG_NULL, "null argument");
+  *n = mc->n;
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_mcsor_get_layout(pmg_mcsor mc, int32_t *pos_of_row)
 {
   PMG_CHECK(mc && pos_of_row, PMG_ERR_ARG_NULL, "null argument");
@@ -598,6 +607,14 @@ pmg_status pmg_mcsor_set_lowrank(pmg_mcsor mc, int32_t k, const double *B_host, 
   return st;
 }
 
+/* the CSR arrays pmg_mcsor_create_csr borrowed become the object's (malloc'd by the caller, freed with the object) */
+void pmg_mcsor_adopt_arrays(pmg_mcsor mc, int32_t *rowptr, int32_t *colidx, double *vals)
+{
+  mc->rowptr_own = rowptr;
+  mc->colidx_own = colidx;
+  mc->vals_own   = vals;
+}
+
 pmg_status pmg_mcsor_destroy(pmg_mcsor *mc)
 {
   if (!mc || !*mc) return PMG_SUCCESS;
@@ -606,6 +623,7 @@ pmg_status pmg_mcsor_destroy(pmg_mcsor *mc)
   free((*mc)->user_colors);
   free((*mc)->rowptr_own);
   free((*mc)->colidx_own);
+  free((*mc)->vals_own);
   free(*mc);
   *mc = NULL;
   return PMG_SUCCESS;

@@ -905,22 +905,17 @@ pmg_status pmg_pc_shell_get_context(pmg_pc pc, void **ctx)
 /* "woodbury" (src/woodbury.c): a sampler for A + B S B^T assembled from ANY sampler of A plus a solver   */
 /* ---------------------------------------------------------------------------------------------------- */
 typedef struct {
-  pmg_pc  solver, sampler; /* owned */
-  pmg_mat Abase;           /* the base operator of the MATLRC matrix, owned copy of the descriptor */
-  int32_t k;
-  double *B, *G;           /* device, n x k column-major (natural numbering) */
-  double *S_sqrt, *wk, *partial, *w; /* device: sqrt|S| (k), work (64), reduction scratch, noisy rhs (n) */
+  pmg_pc       solver, sampler; /* owned */
+  pmg_mat      Abase;           /* the base operator of the MATLRC matrix, owned copy of the descriptor */
+  pmg_woodbury wb;              /* B, G = C (S^-1 + B^T C)^-1 and the dense products (pmg_woodbury.c) */
+  double      *w;               /* device: noisy right-hand side (n) */
 } pc_woodbury;
 
 static pmg_status woodbury_free_setup(pc_woodbury *d)
 {
-  pmg_dev_free(d->B);
-  pmg_dev_free(d->G);
-  pmg_dev_free(d->S_sqrt);
-  pmg_dev_free(d->wk);
-  pmg_dev_free(d->partial);
+  pmg_woodbury_destroy(&d->wb);
   pmg_dev_free(d->w);
-  d->B = d->G = d->S_sqrt = d->wk = d->partial = d->w = NULL;
+  d->w = NULL;
   pmg_mat_destroy(&d->Abase);
   return PMG_SUCCESS;
 }
@@ -995,68 +990,38 @@ static pmg_status woodbury_setup(pmg_pc pc) /* PCSetUp_Woodbury :142-183 + PCWoo
   PMG_CHECK(pc->pmat->lrc_k, PMG_ERR_SUP, "PCWoodbury only supports matrices of type LRC");    /* :161 */
   woodbury_free_setup(d);
   const int32_t n = pc->pmat->n, k = pc->pmat->lrc_k;
-  d->k     = k;
   d->Abase = (pmg_mat)malloc(sizeof *d->Abase);
   PMG_CHECK(d->Abase, PMG_ERR_MEM, "out of host memory");
   *d->Abase       = *pc->pmat; /* MatLRCGetMats(pc->pmat, &A, &B, &S, NULL), :162 */
   d->Abase->lrc_k = 0;
   d->Abase->lrc_B = d->Abase->lrc_S = NULL;
-  double sq[64];
-  for (int c = 0; c < k; ++c) sq[c] = sqrt(fabs(pc->pmat->lrc_S[c])); /* VecSqrtAbs, :177 */
-  PMG_CALL(pmg_dev_upload((void **)&d->B, pc->pmat->lrc_B, sizeof(double) * (size_t)n * k));
-  PMG_CALL(pmg_dev_upload((void **)&d->S_sqrt, sq, sizeof(double) * (size_t)k));
-  PMG_CALL(pmg_dev_alloc((void **)&d->G, sizeof(double) * (size_t)n * k));
-  PMG_CALL(pmg_dev_alloc((void **)&d->wk, sizeof(double) * 64));
-  PMG_CALL(pmg_dev_alloc((void **)&d->partial, sizeof(double) * (size_t)pmgk_lrc_nblocks(n) * k));
+  PMG_CALL(pmg_woodbury_create(n, k, pc->pmat->lrc_B, n, pc->pmat->lrc_S, NULL, &d->wb));
   PMG_CALL(pmg_dev_alloc((void **)&d->w, sizeof(double) * (size_t)n));
   PMG_CALL(pmg_pc_set_operators(d->solver, d->Abase)); /* :178-181 */
   PMG_CALL(pmg_pc_set_operators(d->sampler, d->Abase));
   PMG_CALL(pmg_pc_setup(d->solver));
   PMG_CALL(pmg_pc_setup(d->sampler));
   PMG_CHECK(d->sampler->ops.applyrichardson, PMG_ERR_SUP, "PC type %s does not have applyrichardson", d->sampler->type);
-  /* G = C (S^-1 + B^T C)^-1 with C = solver(B) column by column from a zero guess (:35-50, :52-81) */
-  double    *Cm = NULL, *Sb_dev = NULL;
-  double    *T = (double *)malloc(sizeof(double) * (size_t)k * k), *Sb = (double *)malloc(sizeof(double) * (size_t)k * k);
-  pmg_status st = (T && Sb) ? PMG_SUCCESS : pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
-  if (!st) st = pmg_dev_alloc((void **)&Cm, sizeof(double) * (size_t)n * k);
-  if (!st) st = pmg_dev_alloc((void **)&Sb_dev, sizeof(double) * (size_t)k * k);
-  for (int c = 0; c < k && !st; ++c) {
-    if (hipMemsetAsync(Cm + (size_t)n * c, 0, sizeof(double) * (size_t)n, NULL) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
-    if (!st) st = pmg_pc_apply(d->solver, d->B + (size_t)n * c, Cm + (size_t)n * c, NULL); /* PCApply(wb->solver, b, x), :45 */
+  for (int c = 0; c < k; ++c) { /* C = solver(B) column by column from a zero guess (:35-50) */
+    const double *bc;
+    double       *cc;
+    PMG_CALL(pmg_woodbury_column(d->wb, c, &bc, &cc, NULL));
+    PMG_CALL(pmg_pc_apply(d->solver, bc, cc, NULL)); /* PCApply(wb->solver, b, x), :45 */
   }
-  for (int c = 0; c < k && !st; ++c) { /* tmp = B^T C, :53 */
-    if (pmgk_lrc_btx(n, k, d->B, n, Cm + (size_t)n * c, d->partial, NULL, d->wk, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
-    if (!st && hipMemcpy(T + (size_t)k * c, d->wk, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "download failed");
-  }
-  if (!st) {
-    for (int c = 0; c < k; ++c) T[c + (size_t)k * c] += 1.0 / pc->pmat->lrc_S[c]; /* + S^-1, :66-68 */
-    if (pmg_invert_small(k, T, Sb)) st = pmg_set_error(PMG_ERR_LIB, __FILE__, __LINE__, "S^-1 + B^T M^-1 B is singular");
-  }
-  if (!st && hipMemcpy(Sb_dev, Sb, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "upload failed");
-  if (!st && pmgk_lrc_gemm_small(n, k, Cm, n, Sb_dev, d->G, NULL)) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed"); /* G = C Sb, :78 */
-  if (!st && hipDeviceSynchronize() != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device error while building the Woodbury correction");
-  free(T);
-  free(Sb);
-  pmg_dev_free(Cm);
-  pmg_dev_free(Sb_dev);
-  if (st) return st;
-  pmg_pc_destroy(&d->solver); /* :182 */
+  PMG_CALL(pmg_woodbury_finish(d->wb)); /* G = C (S^-1 + B^T C)^-1, :52-81 */
+  pmg_pc_destroy(&d->solver);           /* :182 */
   return PMG_SUCCESS;
 }
 
 static pmg_status woodbury_applyrichardson(pmg_pc pc, const double *b, double *y, int32_t its, int guesszero, int32_t *outits, void *stream)
 { /* PCApplyRichardson_Woodbury :263-289 */
   (void)guesszero;
-  pc_woodbury  *d = (pc_woodbury *)pc->data;
-  const int32_t n = pc->pmat->n, k = d->k;
+  pc_woodbury *d = (pc_woodbury *)pc->data;
   for (int32_t it = 0; it < its; ++it) {
-    PMG_KERNEL(pmgk_fill_normal_rows(k, pc_seed(pc), pc->counter++, d->wk, stream));      /* VecSetRandomStandardNormal(wb->wk), :275 */
-    PMG_KERNEL(pmgk_lrc_mul(k, d->wk, d->S_sqrt, d->wk, stream));                         /* VecPointwiseMult, :276              */
-    PMG_KERNEL(pmgk_lrc_axpy_cols(n, k, d->B, n, d->wk, 1.0, b, d->w, stream));           /* MatMultAdd(B, wk, b, w), :277       */
+    PMG_CALL(pmg_woodbury_noisy_rhs(d->wb, b, d->w, pc_seed(pc), pc->counter++, stream)); /* w = b + B (sqrt|S| o xi), :275-277 */
     int32_t done = 0;
     PMG_CALL(d->sampler->ops.applyrichardson(d->sampler, d->w, y, 1, 0, &done, stream)); /* one sample of the A-sampler, :278    */
-    PMG_KERNEL(pmgk_lrc_btx(n, k, d->B, n, y, d->partial, NULL, d->wk, stream));          /* wk = B^T y, :280                   */
-    PMG_KERNEL(pmgk_lrc_axpy_cols(n, k, d->G, n, d->wk, -1.0, y, y, stream));             /* y -= G wk, :281-282                */
+    PMG_CALL(pmg_woodbury_correct(d->wb, y, stream));                                     /* y -= G (B^T y), :280-282            */
     PMG_CALL(pc_notify(pc, it, y, stream));
   }
   *outits = its;

@@ -920,3 +920,134 @@ class DistAIJMGMC:
         if getattr(self, "_drv", None) is not None:
             self._drv.destroy()  # collective: disconnect, barrier, destroy
             self._drv = None
+
+
+class CRowBlock:
+    """The multi-rank samplers on MATMPIAIJ row blocks reached through the C-ABI ALONE (pmg_rowblock.c): transport bootstrap,
+    colouring, ghost plans, local operators and the sample loops are C; Python only supplies the byte all-gather callback
+    (torch.distributed here, MPI_Allgather in adapter/, pipes in examples/pmg_bench.c) and device tensors.  This is what a
+    PETSc caller with an MPI_Comm uses; DistMCSOR / DistAIJMGMC above are the round-2 Python builders the C plans are pinned to.
+
+      CRowBlock.sampler(...)  MCSORCreate + MCSORSetUp + the sample loop on a MATMPIAIJ (reference src/mc_sor.c:298-381,553-605)
+      CRowBlock.mgmc(...)     PCGAMGMC on a hierarchy of MATMPIAIJ levels (src/pc_gamgmc.c:157-264)"""
+
+    def __init__(self, rank: int, world: int, group=None, transport: str = "ipc"):
+        import ctypes as C
+
+        from . import capi
+        from .capi import check, lib
+
+        self.rank, self.world = rank, world
+        self.comm, self._keep = capi.torch_host_comm(rank, world, group)
+        self._dist = C.c_void_p()
+        path = capi.torch_rccl_path()
+        check(lib.pmg_dist_create_comm(C.byref(self.comm), transport.encode(), None, path.encode() if path else None, C.byref(self._dist)))
+        self.transport = transport
+        self._mc, self._dm, self._mg, self._rbh = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.nowned = 0
+
+    @property
+    def dist_handle(self):
+        return self._dist
+
+    def sampler(self, row_starts, rowptr, colidx_global, vals, omega=1.0, colors=None, ncolors=0):
+        """this rank's rows with GLOBAL columns (pmg_rowblock_merge_mpiaij of MatMPIAIJGetSeqAIJ's blocks); colors None: the
+        library's first-fit colouring of the global matrix"""
+        import ctypes as C
+
+        import numpy as np
+
+        from .capi import check, lib
+
+        rs = np.ascontiguousarray(row_starts, np.int64)
+        rp, ci, v = np.ascontiguousarray(rowptr, np.int64), np.ascontiguousarray(colidx_global, np.int64), np.ascontiguousarray(vals, np.float64)
+        col = None if colors is None else np.ascontiguousarray(colors, np.int32)
+        self.nowned = int(rs[self.rank + 1] - rs[self.rank])
+        check(lib.pmg_rowblock_sampler_create(C.byref(self.comm), self._dist, rs.ctypes.data, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 64, ncolors, col.ctypes.data if col is not None else None, omega, C.byref(self._mc), C.byref(self._dm)))
+        return self
+
+    def sample(self, b_owned, y_owned, its: int, seed: int, counter0: int = 0, scaled: bool = True, sweep_type: int = SOR_FORWARD_SWEEP) -> int:
+        import ctypes as C
+
+        from .capi import check, lib
+        from .wrappers import _ptr, _stream
+
+        out = C.c_uint64()
+        if self._mg:  # the hierarchy's vectors have one entry per LOCAL row of the finest level (ghost entries ignored)
+            bp, yp = self._pad(b_owned), self._pad(y_owned)  # both stay referenced until the call has been enqueued
+            check(lib.pmg_mgmc_sample(self._mg, _ptr(bp), _ptr(yp), its, 0, seed, counter0, C.byref(out), None, None, _stream()))
+            y_owned.copy_(yp[: self.nowned])
+        else:
+            check(lib.pmg_distmcsor_sample(self._dm, self.nowned, _ptr(b_owned), _ptr(y_owned), its, int(scaled), sweep_type, seed, counter0, C.byref(out), _stream()))
+        return out.value
+
+    def apply(self, b_owned, y_owned, sweep_type: int = SOR_FORWARD_SWEEP):
+        from .capi import check, lib
+        from .wrappers import _ptr, _stream
+
+        check(lib.pmg_distmcsor_apply(self._dm, self.nowned, _ptr(b_owned), _ptr(y_owned), sweep_type, _stream()))
+
+    def _pad(self, t):
+        import torch
+
+        p = torch.zeros(self.nlocal, dtype=torch.float64, device="cuda")
+        p[: self.nowned] = t
+        return p
+
+    def mgmc(self, levels, replicate_below: int = 50000, smoother=(True, 1.0, SOR_FORWARD_SWEEP, 1), lowrank=None):
+        """levels[l] = dict(n=global rows, row0=, A=(rowptr, colidx_global, vals) of this rank's rows, P=(rowptr,
+        colidx_global_coarse, vals) of this rank's rows of P_l (l >= 1)); level 0 = coarsest"""
+        import ctypes as C
+
+        import numpy as np
+
+        from .capi import RbhLevelView, check, lib
+
+        L = len(levels)
+        check(lib.pmg_rbh_create(C.byref(self.comm), L, replicate_below, C.byref(self._rbh)))
+        keep = []
+        for l, Lv in enumerate(levels):
+            rp, ci, v = (np.ascontiguousarray(a_, t_) for a_, t_ in zip(Lv["A"], (np.int64, np.int64, np.float64)))
+            keep += [rp, ci, v]
+            check(lib.pmg_rbh_set_level_operator(self._rbh, l, Lv["n"], Lv["row0"], len(rp) - 1, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 64))
+            if l >= 1:
+                prp, pci, pv = (np.ascontiguousarray(a_, t_) for a_, t_ in zip(Lv["P"], (np.int64, np.int64, np.float64)))
+                keep += [prp, pci, pv]
+                check(lib.pmg_rbh_set_level_interpolation(self._rbh, l, len(prp) - 1, prp.ctypes.data, pci.ctypes.data, pv.ctypes.data, 64))
+        check(lib.pmg_rbh_build(self._rbh))
+        check(lib.pmg_rbh_create_mgmc(self._rbh, self._dist, C.byref(self._mg)))
+        check(lib.pmg_mgmc_set_smoother(self._mg, int(smoother[0]), smoother[1], smoother[2], smoother[3]))
+        view = RbhLevelView()
+        check(lib.pmg_rbh_get_level(self._rbh, L - 1, C.byref(view)))
+        self.nowned, self.nlocal = view.nowned, view.nlocal
+        if lowrank is not None:
+            B, S = lowrank
+            Bl = np.zeros((self.nlocal, len(S)), order="F")
+            Bl[: self.nowned] = B
+            S = np.ascontiguousarray(S, np.float64)
+            check(lib.pmg_mgmc_set_lowrank(self._mg, len(S), Bl.ctypes.data, S.ctypes.data))
+        err = None
+        try:
+            check(lib.pmg_mgmc_setup(self._mg))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        _all_ok(err, None, "row-block hierarchy set-up")
+        lib.pmg_rbh_destroy(C.byref(self._rbh))  # the arrays were borrowed until set-up
+        return self
+
+    def destroy(self):
+        """collective"""
+        import ctypes as C
+
+        from .capi import lib
+
+        if self._mg:
+            lib.pmg_mgmc_destroy(C.byref(self._mg))
+        if self._dm:
+            lib.pmg_distmcsor_destroy(C.byref(self._dm))
+        if self._mc:
+            lib.pmg_mcsor_destroy(C.byref(self._mc))
+        if self._rbh:
+            lib.pmg_rbh_destroy(C.byref(self._rbh))
+        if self._dist:
+            lib.pmg_dist_destroy_comm(C.byref(self.comm), C.byref(self._dist))

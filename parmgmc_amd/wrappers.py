@@ -422,6 +422,59 @@ class MGMC:
             pass
 
 
+class WoodburySampler:
+    """PCWOODBURY (reference src/woodbury.c): posterior sampler for A + B diag(S) B^T from ANY sampler of A plus a solver --
+    on one device or on rows distributed over ranks (z-slabs, row blocks): B_rows = this rank's rows of B (n x k), vectors in
+    natural order over those rows; `dist_handle` = the C handle of a transport of the ranks (ctypes void pointer) or None.
+      solve(b, x)            x <- (approximately) A^-1 b from the zero guess x holds (device tensors), collective
+      sample(w, y, counter)  one sample of the A-sampler on right-hand side w, y updated in place, collective"""
+
+    def __init__(self, B_rows, S, solve, sample, dist_handle=None):
+        import torch
+
+        B = np.asfortranarray(B_rows, np.float64)
+        S = np.ascontiguousarray(S, np.float64)
+        self.n, self.k = B.shape
+        assert len(S) == self.k
+        self._h = C.c_void_p()
+        self._sample = sample
+        check(lib.pmg_woodbury_create(self.n, self.k, B.ctypes.data, max(self.n, 1), S.ctypes.data, dist_handle, C.byref(self._h)))
+        for c in range(self.k):  # C = solver(B) column by column from a zero guess (src/woodbury.c:35-50)
+            b = torch.as_tensor(np.ascontiguousarray(B[:, c]), device="cuda")
+            x = torch.zeros(self.n, dtype=torch.float64, device="cuda")
+            solve(b, x)
+            check(lib.pmg_woodbury_set_c_column(self._h, c, _ptr(x), _stream()))
+        torch.cuda.synchronize()
+        check(lib.pmg_woodbury_finish(self._h))
+        self._w = torch.zeros(self.n, dtype=torch.float64, device="cuda")
+
+    def correction(self):
+        G = np.zeros((self.n, self.k), order="F")
+        check(lib.pmg_woodbury_get_correction(self._h, G.ctypes.data))
+        return G
+
+    def run(self, b, y, its: int, seed: int, counter0: int = 0, callback=None) -> int:
+        """PCApplyRichardson_Woodbury (src/woodbury.c:263-289); sample `it` uses noise counter counter0 + it for the k-vector
+        and hands the same counter to the A-sampler"""
+        for it in range(its):
+            check(lib.pmg_woodbury_noisy_rhs(self._h, _ptr(b), _ptr(self._w), seed ^ 0x5851F42D4C957F2D, counter0 + it, _stream()))
+            self._sample(self._w, y, counter0 + it)
+            check(lib.pmg_woodbury_correct(self._h, _ptr(y), _stream()))
+            if callback is not None:
+                callback(it, y)
+        return counter0 + its
+
+    def destroy(self):
+        if self._h:
+            check(lib.pmg_woodbury_destroy(C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 def vec_set_random_standard_normal(x, seed: int, counter: int = 0):
     """VecSetRandomStandardNormal (reference src/parmgmc.c:70-116) on the counter-based source."""
     check(lib.pmg_vec_set_random_standard_normal(x.numel(), _ptr(x), seed, counter, _stream()))
