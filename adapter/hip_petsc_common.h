@@ -128,9 +128,15 @@ static inline PetscErrorCode HipCallSampleCallback(PetscErrorCode (*scb)(PetscIn
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-/* seed of the library's counter-based noise = seed of ParMGMC's global PetscRandom (reference src/parmgmc.c:56-68,
-   -random_seed): one stream definition for all PCs of a process, like the reference's shared generator */
-static inline PetscErrorCode HipNoiseSeed(uint64_t *seed)
+/* Seed of a PC's counter-based noise.  The reference's PCs all draw from ONE advancing PetscRandom (src/parmgmc.c:56-68), so
+   two PCs of a process never see the same values.  The library's noise is a pure function of (seed, counter, row): a PC
+   therefore gets a stream of its own -- the seed of ParMGMC's global PetscRandom (-random_seed) mixed with a process-wide
+   instance number handed out in PCCreate (ParMGMCHipNextStreamId, pc_hipgamgmc.c).  PCs are created collectively and in the
+   same order on every rank, so the ranks of a distributed PC agree on the number; two mcgibbs smoothers on the levels of a
+   PETSc PCMG, a cholsampler beside a Gibbs PC, or two independent chains draw independent values.  (Same mixing as the
+   library's own PC mirror: pc_seed in pmg_pc.c.) */
+PETSC_EXTERN uint64_t ParMGMCHipNextStreamId(void);
+static inline PetscErrorCode HipNoiseSeed(uint64_t stream_id, uint64_t *seed)
 {
   PetscRandom r;
   PetscInt64  s;
@@ -139,7 +145,72 @@ static inline PetscErrorCode HipNoiseSeed(uint64_t *seed)
   PetscCall(ParMGMCGetPetscRandom(&r));
   PetscCall(PetscRandomGetSeed(r, &s));
   PetscCall(PetscRandomDestroy(&r)); /* drop the reference ParMGMCGetPetscRandom took */
-  *seed = (uint64_t)s;
+  *seed = (uint64_t)s + 0xD1B54A32D192ED03ull * (stream_id + 1);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ---- more than one rank: one rank = one device ------------------------------------------------------------------- */
+/* the byte all-gather the library's row-block set-up calls back into (pmg_host_comm, include/parmgmc_hip.h) */
+static inline int HipMPIAllgather(void *ctx, const void *send, int64_t nbytes, void *recv)
+{
+  return MPI_Allgather((void *)send, (int)nbytes, MPI_BYTE, recv, (int)nbytes, MPI_BYTE, *(MPI_Comm *)ctx) == MPI_SUCCESS ? 0 : 1;
+}
+
+/* *store must outlive hc (it is what hc->ctx points to) */
+static inline PetscErrorCode HipHostComm(MPI_Comm comm, MPI_Comm *store, pmg_host_comm *hc)
+{
+  PetscMPIInt rank, size;
+
+  PetscFunctionBeginUser;
+  PetscCallMPI(MPI_Comm_rank(comm, &rank));
+  PetscCallMPI(MPI_Comm_size(comm, &size));
+  *store        = comm;
+  hc->rank      = (int32_t)rank;
+  hc->nranks    = (int32_t)size;
+  hc->allgather = HipMPIAllgather;
+  hc->ctx       = store;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* the halo / all-gather transport of the ranks of `hc`: "ipc" (hipIpc peer stores + flag words, ranks of ONE node), else RCCL.
+   Both attempts are collective and agreed on inside the library, so every rank takes the same branch.  g: this rank's
+   z-slab of a DMDA operator, or NULL for row blocks. */
+static inline PetscErrorCode HipCreateTransport(const pmg_host_comm *hc, pmg_grid g, pmg_dist *d)
+{
+  PetscFunctionBeginUser;
+  if (pmg_dist_create_comm(hc, "ipc", g, NULL, d) != 0) PMGCall(pmg_dist_create_comm(hc, "rccl", g, NULL, d));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* This rank's rows of a MATMPIAIJ with GLOBAL column indices, entries in the order of the sequential row: the blocks of
+   MatMPIAIJGetSeqAIJ (reference src/mc_sor.c:308) merged by pmg_rowblock_merge_mpiaij.  colstart: first global column of
+   the diagonal block (= first owned row for a square operator, the coarse ownership start for an interpolation).  The three
+   arrays are PetscMalloc'ed (caller frees); *starts (nranks + 1, PetscMalloc'ed) = MatGetOwnershipRanges as int64. */
+static inline PetscErrorCode HipMPIAIJRows(Mat A, int64_t **rp, int64_t **ci, double **v, int64_t **starts, PetscInt *nloc)
+{
+  Mat             Ad, Ao;
+  const PetscInt *garray, *ia, *ja, *ib, *jb, *ranges;
+  PetscScalar    *aa, *ab;
+  PetscInt        m, cstart;
+  PetscMPIInt     size;
+
+  PetscFunctionBeginUser;
+  PetscCall(MatMPIAIJGetSeqAIJ(A, &Ad, &Ao, &garray));
+  PetscCall(MatSeqAIJGetCSRAndMemType(Ad, &ia, &ja, &aa, NULL));
+  PetscCall(MatSeqAIJGetCSRAndMemType(Ao, &ib, &jb, &ab, NULL));
+  PetscCall(MatGetLocalSize(A, &m, NULL));
+  PetscCall(MatGetOwnershipRangeColumn(A, &cstart, NULL));
+  PetscCall(PetscMalloc1((size_t)m + 1, rp));
+  PetscCall(PetscMalloc1((size_t)(ia[m] + ib[m]) + 1, ci));
+  PetscCall(PetscMalloc1((size_t)(ia[m] + ib[m]) + 1, v));
+  PMGCall(pmg_rowblock_merge_mpiaij((int32_t)m, (int64_t)cstart, ia, ja, aa, ib, jb, ab, garray, PMG_IDX_WIDTH, PMG_ROWBLOCK_ORDER_GLOBAL, *rp, *ci, *v));
+  if (starts) {
+    PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)A), &size));
+    PetscCall(MatGetOwnershipRanges(A, &ranges));
+    PetscCall(PetscMalloc1((size_t)size + 1, starts));
+    for (PetscMPIInt r = 0; r <= size; ++r) (*starts)[r] = (int64_t)ranges[r];
+  }
+  if (nloc) *nloc = m;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -166,8 +237,11 @@ PETSC_EXTERN PetscErrorCode PCCreate_HipSORGibbs(PC);
 PETSC_EXTERN PetscErrorCode PCCreate_HipMulticolorGibbs(PC);
 PETSC_EXTERN PetscErrorCode PCCreate_HipGAMGMC(PC);
 PETSC_EXTERN PetscErrorCode PCCreate_HipCholSampler(PC);
-/* PCRegister of the four names above under the reference's type names "sorgibbs", "mcgibbs", "gamgmc",
-   "cholsampler": call it from ParMGMCRegisterPCAll (reference src/parmgmc.c:44-54) in place of the CPU constructors */
+PETSC_EXTERN PetscErrorCode PCCreate_HipPARSOR(PC);
+PETSC_EXTERN PetscErrorCode PCCreate_HipWoodbury(PC);
+/* PCRegister of the six constructors under the reference's six type names "sorgibbs", "mcgibbs", "gamgmc", "cholsampler",
+   "parsor", "woodbury" (include/parmgmc/parmgmc.h:26-31): call it from ParMGMCRegisterPCAll (reference src/parmgmc.c:44-54)
+   in place of the CPU constructors */
 PETSC_EXTERN PetscErrorCode ParMGMCHipRegisterPCAll(void);
 
 #endif /* PARMGMC_HIP_HAVE_PETSC */

@@ -19,8 +19,16 @@ typedef struct {
   PC          mg; /* PETSc's hierarchy builder; never applied */
   char        mgtype[64];
   pmg_mgmc    h;
-  uint64_t    seed, counter;
+  uint64_t    seed, counter, stream_id;
   HipStageBuf bbuf, ybuf;
+  /* more than one rank (one rank = one device): row blocks of MATMPIAIJ levels, or z-slabs of a DMDA */
+  pmg_dist      transport;
+  pmg_grid      slab;
+  pmg_host_comm hc;
+  MPI_Comm      hc_comm;
+  pmg_rbh       rbh;            /* row-block builder, alive from PCGAMGMC_SetUpHierarchy to pmg_mgmc_setup */
+  PetscInt      nowned, nlocal; /* row blocks: the library's fine-level vectors carry one entry per LOCAL row (owned, then ghosts) */
+  HipStageBuf   bpad, ypad;
 
   void *cbctx;
   PetscErrorCode (*scb)(PetscInt, Vec, void *);
@@ -31,24 +39,32 @@ typedef struct {
 typedef struct {
   PC_HipGAMGMC  *pg;
   HipVecAccess  *y;
+  double        *ypad; /* row blocks: the library's vector (owned rows, then ghost rows); NULL: it works on y itself */
   PetscErrorCode ierr;
 } HipTrampoline;
 
 static int HipSampleTrampoline(int32_t it, const double *y_nat_dev, int32_t n, void *ctx)
 {
   HipTrampoline *t = (HipTrampoline *)ctx;
-  (void)y_nat_dev; /* == t->y->dev: pmg_mgmc_sample writes the sample into the caller's y before it calls back */
+  (void)y_nat_dev; /* == t->y->dev (or t->ypad): pmg_mgmc_sample writes the sample into the caller's y before it calls back */
   (void)n;
+  if (t->ypad && hipMemcpy(t->y->dev, t->ypad, sizeof(double) * (size_t)t->pg->nowned, hipMemcpyDeviceToDevice) != hipSuccess) return PETSC_ERR_GPU;
   t->ierr = HipCallSampleCallback(t->pg->scb, t->pg->cbctx, (PetscInt)it, t->y, NULL); /* pg->scb(it, y, ctx), src/pc_gamgmc.c:258 */
+  if (!t->ierr && t->ypad && hipMemcpy(t->ypad, t->y->dev, sizeof(double) * (size_t)t->pg->nowned, hipMemcpyDeviceToDevice) != hipSuccess) return PETSC_ERR_GPU; /* the callback may have changed y */
   return t->ierr ? (int)t->ierr : 0;
 }
 
 static PetscErrorCode HipGAMGMCRelease(PC_HipGAMGMC *pg)
 {
   PetscFunctionBeginUser;
-  PMGCall(pmg_mgmc_destroy(&pg->h));
+  PMGCall(pmg_mgmc_destroy(&pg->h)); /* before the transport and the slab it borrows */
+  pmg_rbh_destroy(&pg->rbh);
+  if (pg->transport) PMGCall(pmg_dist_destroy_comm(&pg->hc, &pg->transport));
+  PMGCall(pmg_grid_destroy(&pg->slab));
   PetscCall(HipStageBufFree(&pg->bbuf));
   PetscCall(HipStageBufFree(&pg->ybuf));
+  PetscCall(HipStageBufFree(&pg->bpad));
+  PetscCall(HipStageBufFree(&pg->ypad));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -99,8 +115,115 @@ static PetscErrorCode HipSeqAIJArrays(Mat A, const char *what, PetscInt l, const
 
   PetscFunctionBeginUser;
   PetscCall(PetscObjectTypeCompare((PetscObject)A, MATSEQAIJ, &isseq));
-  PetscCheck(isseq, PetscObjectComm((PetscObject)A), PETSC_ERR_SUP, "%s of level %" PetscInt_FMT " is not MATSEQAIJ: one rank per device hands over sequential matrices (a DMDA split in z uses pmg_mgmc_create_dmda_slab, INTEGRATION.md)", what, l);
+  PetscCheck(isseq, PetscObjectComm((PetscObject)A), PETSC_ERR_SUP, "%s of level %" PetscInt_FMT " is not MATSEQAIJ", what, l);
   PetscCall(MatSeqAIJGetCSRAndMemType(A, ia, ja, aa, NULL));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ---- more than one rank ------------------------------------------------------------------------------------------ */
+/* Is pc->dm a 3-D DMDA split in z only, and `A` the operator of MatAssembleShiftedLaplaceFD on it (reference src/problems.c:
+   14-75: off-diagonals -h2, diagonal kappa^2 + (#neighbours) h2, h2 = 1/(nx-1)^2)?  Then the hierarchy is the library's own
+   DMDA hierarchy on z-slabs (matrix-free fine level, class-stencil Galerkin levels: pmg_mgmc_create_dmda_slab) and *kappa
+   is read off the first local row.  Every rank checks ALL its rows; the verdict is agreed with an all-reduce. */
+static PetscErrorCode HipDetectDMDASlab(PC pc, Mat A, PetscBool *yes, PetscInt dims[3], PetscInt *zs, PetscInt *zm, PetscReal *kappa)
+{
+  PetscBool       isda = PETSC_FALSE;
+  PetscInt        dim, M, N, P, m, n, p, dof, sw, xs, ys, xm, ym, rstart, rend;
+  PetscMPIInt     ok = 1, all = 0;
+  DMDAStencilType st;
+
+  PetscFunctionBeginUser;
+  *yes = PETSC_FALSE;
+  if (pc->dm) PetscCall(PetscObjectTypeCompare((PetscObject)pc->dm, DMDA, &isda));
+  if (!isda) ok = 0;
+  if (ok) {
+    PetscCall(DMDAGetInfo(pc->dm, &dim, &M, &N, &P, &m, &n, &p, &dof, &sw, NULL, NULL, NULL, &st));
+    if (dim != 3 || dof != 1 || m != 1 || n != 1 || ((M - 1) % 2) || ((N - 1) % 2) || ((P - 1) % 2)) ok = 0;
+  }
+  if (ok) {
+    const PetscReal h2 = 1.0 / (PetscReal)((M - 1) * (M - 1));
+    PetscReal       k2 = -1.0;
+    PetscCall(DMDAGetCorners(pc->dm, &xs, &ys, zs, &xm, &ym, zm));
+    PetscCall(MatGetOwnershipRange(A, &rstart, &rend));
+    if (rend - rstart != M * N * (*zm)) ok = 0;
+    for (PetscInt r = rstart; r < rend && ok; ++r) { /* z-slabs: PETSc's ordering of the owned points IS the natural order of the slab */
+      const PetscInt     q = r - rstart, i = q % M, j = (q / M) % N, k = *zs + q / (M * N);
+      const PetscInt     nnb = (i > 0) + (i < M - 1) + (j > 0) + (j < N - 1) + (k > 0) + (k < P - 1);
+      PetscInt           ncols;
+      const PetscInt    *cols;
+      const PetscScalar *vals;
+      PetscCall(MatGetRow(A, r, &ncols, &cols, &vals));
+      if (ncols != nnb + 1) ok = 0;
+      for (PetscInt c = 0; c < ncols && ok; ++c) {
+        if (cols[c] == r) {
+          const PetscReal kk = vals[c] - (PetscReal)nnb * h2;
+          if (k2 < 0) k2 = kk;
+          else if (PetscAbsReal(kk - k2) > 1e-12 * PetscAbsReal(vals[c])) ok = 0;
+        } else if (vals[c] != -h2) ok = 0;
+      }
+      PetscCall(MatRestoreRow(A, r, &ncols, &cols, &vals));
+    }
+    if (k2 < 0) ok = 0;
+    *kappa  = ok ? PetscSqrtReal(k2) : 0;
+    dims[0] = M, dims[1] = N, dims[2] = P;
+  }
+  PetscCallMPI(MPI_Allreduce(&ok, &all, 1, MPI_INT, MPI_MIN, PetscObjectComm((PetscObject)pc)));
+  *yes = (PetscBool)(all == 1);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* PCGAMGMC_SetUpHierarchy on MATMPIAIJ levels (src/pc_gamgmc.c:157-223): every level operator and interpolation PCMG / PCGAMG
+   built is handed to the library as this rank's rows with global columns; the library replicates the small levels, colours
+   the others, builds the rows of P^T each rank owns and the ghost plans (pmg_rbh_*), all through MPI_Allgather */
+static PetscErrorCode HipGAMGMCRowBlocks(PC pc, PetscInt levels)
+{
+  PC_HipGAMGMC *pg = (PC_HipGAMGMC *)pc->data;
+  pmg_rbh       rbh = NULL;
+  PetscInt      repl = 50000;
+  const char   *prefix;
+
+  PetscFunctionBeginUser;
+  PetscCall(PCGetOptionsPrefix(pc, &prefix));
+  PetscCall(PetscOptionsGetInt(NULL, prefix, "-pc_gamgmc_hip_replicate_below", &repl, NULL)); /* levels with at most that many rows run redundantly on every rank */
+  PetscCall(HipCreateTransport(&pg->hc, NULL, &pg->transport));
+  PMGCall(pmg_rbh_create(&pg->hc, (int32_t)levels, (int64_t)repl, &rbh));
+  for (PetscInt l = 0; l < levels; ++l) {
+    KSP      ksp;
+    PC       pcl;
+    Mat      A, Ip;
+    int64_t *rp, *ci;
+    double  *v;
+    PetscInt nloc, n, rstart;
+
+    PetscCall(PCMGGetSmoother(pg->mg, l, &ksp));
+    PetscCall(KSPGetPC(ksp, &pcl));
+    PetscCall(PCGetOperators(pcl, NULL, &A));
+    PetscCall(MatGetSize(A, &n, NULL));
+    PetscCall(MatGetOwnershipRange(A, &rstart, NULL));
+    PetscCall(HipMPIAIJRows(A, &rp, &ci, &v, NULL, &nloc));
+    PMGCall(pmg_rbh_set_level_operator(rbh, (int32_t)l, (int64_t)n, (int64_t)rstart, (int64_t)nloc, rp, ci, v, 64)); /* copied */
+    PetscCall(PetscFree(rp));
+    PetscCall(PetscFree(ci));
+    PetscCall(PetscFree(v));
+    if (l > 0) {
+      PetscCall(PCMGGetInterpolation(pg->mg, l, &Ip));
+      PetscCall(HipMPIAIJRows(Ip, &rp, &ci, &v, NULL, &nloc));
+      PMGCall(pmg_rbh_set_level_interpolation(rbh, (int32_t)l, (int64_t)nloc, rp, ci, v, 64));
+      PetscCall(PetscFree(rp));
+      PetscCall(PetscFree(ci));
+      PetscCall(PetscFree(v));
+    }
+    if (l == levels - 1) pg->nowned = nloc;
+    PetscCall(PCReset(pcl)); /* the level sampler PETSc created is never applied */
+  }
+  PMGCall(pmg_rbh_build(rbh));
+  PMGCall(pmg_rbh_create_mgmc(rbh, pg->transport, &pg->h));
+  {
+    pmg_rbh_level_view view;
+    PMGCall(pmg_rbh_get_level(rbh, (int32_t)levels - 1, &view));
+    pg->nlocal = view.nlocal;
+  }
+  pg->rbh = rbh; /* its arrays stay borrowed until pmg_mgmc_setup: PCSetUp destroys it afterwards */
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -115,9 +238,15 @@ static PetscErrorCode PCSetUp_HipGAMGMC(PC pc)
   char          lvl_type[64] = PCSORGIBBS, coarse_type[64] = PCCHOLSAMPLER;
   PetscReal     omega = 1.0;
   MatSORType    sweep = SOR_FORWARD_SWEEP;
+  PetscMPIInt   size;
+  PetscBool     slab = PETSC_FALSE;
 
   PetscFunctionBeginUser;
   PMGCall(pmg_mgmc_destroy(&pg->h));
+  pmg_rbh_destroy(&pg->rbh);
+  if (pg->transport) PMGCall(pmg_dist_destroy_comm(&pg->hc, &pg->transport));
+  PMGCall(pmg_grid_destroy(&pg->slab));
+  PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)pc), &size));
   PetscCall(PCSetType(pg->mg, pg->mgtype));
   PetscCall(PCGetOptionsPrefix(pc, &prefix));
   PetscCall(PCSetOptionsPrefix(pg->mg, prefix));
@@ -159,8 +288,26 @@ static PetscErrorCode PCSetUp_HipGAMGMC(PC pc)
 
   /* hand the hierarchy over, level 0 = coarsest as in PCMG (src/pc_gamgmc.c:165-176) */
   PetscCall(PCMGGetLevels(pg->mg, &levels));
-  PMGCall(pmg_mgmc_create_hierarchy((int32_t)levels, &pg->h));
-  for (PetscInt l = 0; l < levels; ++l) {
+  pg->nowned = pg->nlocal = 0;
+  if (size > 1) { /* one rank = one device */
+    PetscInt  dims[3], zs, zm;
+    PetscReal kappa;
+
+    PetscCall(HipHostComm(PetscObjectComm((PetscObject)pc), &pg->hc_comm, &pg->hc));
+    if (strcmp(pg->mgtype, PCMG) == 0) PetscCall(HipDetectDMDASlab(pc, P, &slab, dims, &zs, &zm, &kappa));
+    if (slab) { /* DMDA split in z: the library's own hierarchy on z-slabs, halo exchange over xGMI */
+      int32_t *cuts, z0 = (int32_t)zs;
+      PetscCall(PetscMalloc1((size_t)size + 1, &cuts));
+      PetscCallMPI(MPI_Allgather(&z0, 1, MPI_INT, cuts, 1, MPI_INT, PetscObjectComm((PetscObject)pc)));
+      cuts[size] = (int32_t)dims[2];
+      PMGCall(pmg_grid_create((int32_t)dims[0], (int32_t)dims[1], (int32_t)dims[2], (int32_t)zs, (int32_t)zm, kappa, &pg->slab));
+      PetscCall(HipCreateTransport(&pg->hc, pg->slab, &pg->transport));
+      PMGCall(pmg_mgmc_create_dmda_slab((int32_t)dims[0], (int32_t)dims[1], (int32_t)dims[2], kappa, (int32_t)levels, pg->slab, pg->transport, cuts, &pg->h));
+      PetscCall(PetscFree(cuts));
+      pg->nowned = pg->nlocal = dims[0] * dims[1] * zm;
+    } else PetscCall(HipGAMGMCRowBlocks(pc, levels)); /* MATMPIAIJ levels by row blocks */
+  } else PMGCall(pmg_mgmc_create_hierarchy((int32_t)levels, &pg->h));
+  for (PetscInt l = 0; l < levels && size == 1; ++l) {
     KSP             ksp;
     PC              pcl;
     Mat             A, Ip;
@@ -193,15 +340,30 @@ static PetscErrorCode PCSetUp_HipGAMGMC(PC pc)
     const PetscScalar *B, *Sarr;
     PetscScalar       *Bcopy;
 
-    PetscCall(HipGetLRC(pc->pmat, &Abase, &k, &B, &Bcopy, &Bmat, &S));
-    PetscCall(VecGetArrayRead(S, &Sarr));
-    PMGCall(pmg_mgmc_set_lowrank(pg->h, (int32_t)k, Bcopy ? Bcopy : B, Sarr));
+    if (size == 1) {
+      PetscCall(HipGetLRC(pc->pmat, &Abase, &k, &B, &Bcopy, &Bmat, &S));
+      PetscCall(VecGetArrayRead(S, &Sarr));
+      PMGCall(pmg_mgmc_set_lowrank(pg->h, (int32_t)k, Bcopy ? Bcopy : B, Sarr));
+    } else { /* this rank's rows of the dense MPI matrix B, one column of nlocal entries each (ghost entries zero) */
+      PetscInt lda, mloc;
+      PetscCall(MatLRCGetMats(pc->pmat, &Abase, &Bmat, &S, NULL));
+      PetscCall(MatGetSize(Bmat, NULL, &k));
+      PetscCall(MatGetLocalSize(Bmat, &mloc, NULL));
+      PetscCheck(mloc == pg->nowned, PetscObjectComm((PetscObject)pc), PETSC_ERR_ARG_SIZ, "the rows of B must be distributed like the rows of A");
+      PetscCall(MatDenseGetLDA(Bmat, &lda));
+      PetscCall(MatDenseGetArrayRead(Bmat, &B));
+      PetscCall(PetscCalloc1((size_t)pg->nlocal * (size_t)k, &Bcopy));
+      for (PetscInt c = 0; c < k; ++c) PetscCall(PetscArraycpy(Bcopy + (size_t)pg->nlocal * c, B + (size_t)lda * c, mloc));
+      PetscCall(VecGetArrayRead(S, &Sarr));
+      PMGCall(pmg_mgmc_set_lowrank(pg->h, (int32_t)k, Bcopy, Sarr));
+    }
     PetscCall(VecRestoreArrayRead(S, &Sarr));
     PetscCall(MatDenseRestoreArrayRead(Bmat, &B));
     PetscCall(PetscFree(Bcopy));
   }
   PMGCall(pmg_mgmc_setup(pg->h)); /* colours and uploads every level; the PETSc matrices are no longer read afterwards */
-  PetscCall(HipNoiseSeed(&pg->seed));
+  pmg_rbh_destroy(&pg->rbh);
+  PetscCall(HipNoiseSeed(pg->stream_id, &pg->seed));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -221,11 +383,29 @@ static PetscErrorCode PCApplyRichardson_HipGAMGMC(PC pc, Vec b, Vec y, Vec w, Pe
   PetscCall(HipVecGet(y, PETSC_TRUE, &pg->ybuf, &ay));
   tr.pg   = pg;
   tr.y    = &ay;
+  tr.ypad = NULL;
   tr.ierr = PETSC_SUCCESS;
   {
-    const int rc = pmg_mgmc_sample(pg->h, ab.dev, ay.dev, (int32_t)its, (int)guesszero, pg->seed, pg->counter, &pg->counter, pg->scb ? HipSampleTrampoline : NULL, &tr, NULL);
+    const double *bdev = ab.dev;
+    double       *ydev = ay.dev;
+    if (pg->nlocal > pg->nowned) { /* row blocks: one entry per local row of the finest level, the ghost entries are the library's */
+      for (int q = 0; q < 2; ++q) {
+        HipStageBuf *sb = q ? &pg->ypad : &pg->bpad;
+        if (sb->cap < pg->nlocal) {
+          PetscCall(HipStageBufFree(sb));
+          PMGHip(hipMalloc((void **)&sb->buf, sizeof(double) * (size_t)pg->nlocal));
+          PMGHip(hipMemset(sb->buf, 0, sizeof(double) * (size_t)pg->nlocal));
+          sb->cap = pg->nlocal;
+        }
+      }
+      PMGHip(hipMemcpy(pg->bpad.buf, ab.dev, sizeof(double) * (size_t)pg->nowned, hipMemcpyDeviceToDevice));
+      PMGHip(hipMemcpy(pg->ypad.buf, ay.dev, sizeof(double) * (size_t)pg->nowned, hipMemcpyDeviceToDevice));
+      bdev = pg->bpad.buf, ydev = tr.ypad = pg->ypad.buf;
+    }
+    const int rc = pmg_mgmc_sample(pg->h, bdev, ydev, (int32_t)its, (int)guesszero, pg->seed, pg->counter, &pg->counter, pg->scb ? HipSampleTrampoline : NULL, &tr, NULL);
     PetscCall(tr.ierr); /* an error raised inside the user's callback keeps its own stack */
     PMGCall(rc);
+    if (tr.ypad) PMGHip(hipMemcpy(ay.dev, tr.ypad, sizeof(double) * (size_t)pg->nowned, hipMemcpyDeviceToDevice));
   }
   PetscCall(HipVecRestore(&ay, NULL));
   PetscCall(HipVecRestore(&ab, NULL));
@@ -302,6 +482,7 @@ PetscErrorCode PCCreate_HipGAMGMC(PC pc)
 
   PetscFunctionBeginUser;
   PetscCall(PetscNew(&pg));
+  pg->stream_id = ParMGMCHipNextStreamId();
   PetscCall(PCCreate(PetscObjectComm((PetscObject)pc), &pg->mg));
   PetscCall(PetscStrncpy(pg->mgtype, PCGAMG, sizeof(pg->mgtype))); /* the reference's default, src/pc_gamgmc.c:388 */
 
@@ -317,7 +498,10 @@ PetscErrorCode PCCreate_HipGAMGMC(PC pc)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-/* ---- registration: the body of ParMGMCRegisterPCAll (reference src/parmgmc.c:44-54) for the four device samplers ---- */
+/* ---- registration: the body of ParMGMCRegisterPCAll (reference src/parmgmc.c:44-54), all six type names ----------- */
+static uint64_t parmgmc_hip_stream_ids; /* process-wide: one noise stream per PC instance (hip_petsc_common.h, HipNoiseSeed) */
+uint64_t        ParMGMCHipNextStreamId(void) { return parmgmc_hip_stream_ids++; }
+
 PetscErrorCode ParMGMCHipRegisterPCAll(void)
 {
   PetscFunctionBeginUser;
@@ -325,6 +509,8 @@ PetscErrorCode ParMGMCHipRegisterPCAll(void)
   PetscCall(PCRegister(PCMCGIBBS, PCCreate_HipMulticolorGibbs));
   PetscCall(PCRegister(PCGAMGMC, PCCreate_HipGAMGMC));
   PetscCall(PCRegister(PCCHOLSAMPLER, PCCreate_HipCholSampler));
+  PetscCall(PCRegister(PCPARSOR, PCCreate_HipPARSOR));
+  PetscCall(PCRegister(PCWOODBURY, PCCreate_HipWoodbury));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

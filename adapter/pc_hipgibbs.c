@@ -7,9 +7,14 @@
  * Both fill pc->ops exactly as the reference constructors do (setup, apply [sorgibbs], applyrichardson, destroy,
  * reset, setfromoptions, view, and the composed "PCSetSampleCallback_C"), keep the reference's option names and
  * callback / deleter semantics, and forward the arithmetic to libparmgmc_hip through its C-ABI:
- *   PCSetUp            -> pmg_mcsor_create_csr_idx on the arrays of MatSeqAIJGetCSRAndMemType (src/mc_sor.c:250),
- *                         + pmg_mcsor_set_lowrank for a MATLRC operator (src/mc_sor.c:572-595)
- *   PCApplyRichardson  -> pmg_mcsor_sample (src/pc_mcgibbs.c:155-188 / src/pc_sorgibbs.c:115-134)
+ *   PCSetUp            -> MATSEQAIJ: pmg_mcsor_create_csr_idx on the arrays of MatSeqAIJGetCSRAndMemType (src/mc_sor.c:250),
+ *                         + pmg_mcsor_set_lowrank for a MATLRC operator (src/mc_sor.c:572-595);
+ *                         MATMPIAIJ on more than one rank (one rank = one device; MCSORSetUp's MPIAIJ branch, src/mc_sor.c:
+ *                         152-214,553-605): MatMPIAIJGetSeqAIJ's blocks merged (pmg_rowblock_merge_mpiaij), the ipc / RCCL
+ *                         transport bootstrapped through MPI_Allgather (pmg_dist_create_comm), colouring + ghost plan +
+ *                         local operator + C sample loop from pmg_rowblock_sampler_create, MATLRC via pmg_distmcsor_set_lowrank
+ *   PCApplyRichardson  -> pmg_mcsor_sample / pmg_distmcsor_sample (src/pc_mcgibbs.c:155-188 / src/pc_sorgibbs.c:115-134;
+ *                         MCSORApply_MPIAIJ src/mc_sor.c:298-381: one ghost update per colour)
  *   PCApply (sorgibbs) -> y = 0, one sample (src/pc_sorgibbs.c:105-113)
  * Noise: counter-based (seed, sample counter) instead of the sequential PetscRandom stream; the counter lives in the
  * PC, so consecutive KSPSolve calls continue one chain.
@@ -21,6 +26,13 @@
 
 typedef struct {
   pmg_mcsor   mc;
+  /* more than one rank: row block of a MATMPIAIJ */
+  pmg_distmcsor dm;
+  pmg_dist      transport;
+  pmg_host_comm hc;
+  MPI_Comm      hc_comm;
+  PetscInt      nowned;
+  uint64_t      stream_id; /* this PC's noise stream (HipNoiseSeed) */
   PetscBool   scaled;   /* PETSC_TRUE: mcgibbs (noise scaled by sqrt((2-omega)/omega)); PETSC_FALSE: sorgibbs (omega = 1) */
   PetscReal   omega;
   MatSORType  type;
@@ -37,7 +49,9 @@ typedef struct {
 static PetscErrorCode HipGibbsRelease(PC_HipGibbs *hg)
 {
   PetscFunctionBeginUser;
+  PMGCall(pmg_distmcsor_destroy(&hg->dm));
   PMGCall(pmg_mcsor_destroy(&hg->mc));
+  if (hg->transport) PMGCall(pmg_dist_destroy_comm(&hg->hc, &hg->transport)); /* collective, like PCReset / PCDestroy themselves */
   PetscCall(HipStageBufFree(&hg->bbuf));
   PetscCall(HipStageBufFree(&hg->ybuf));
   if (hg->del_scb) { /* reference src/pc_sorgibbs.c:153-156,173-176 */
@@ -63,6 +77,55 @@ static PetscErrorCode PCDestroy_HipGibbs(PC pc)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* MCSORSetUp on a MATMPIAIJ (reference src/mc_sor.c:553-605 with MatCreateScatters :152-214 and the parallel colouring
+   :383-395): everything behind the C-ABI, the only collective it needs from here is MPI_Allgather */
+static PetscErrorCode HipGibbsSetUpMPIAIJ(PC pc, Mat A, PetscBool islrc)
+{
+  PC_HipGibbs *hg = (PC_HipGibbs *)pc->data;
+  int64_t     *rp, *ci, *starts;
+  double      *v;
+  PetscBool    ismpi;
+
+  PetscFunctionBeginUser;
+  PetscCall(PetscObjectTypeCompare((PetscObject)A, MATMPIAIJ, &ismpi));
+  PetscCheck(ismpi, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "Matrix type not supported (MATSEQAIJ, MATMPIAIJ, or MATLRC over one of them)"); /* src/mc_sor.c:568 */
+  PetscCheck(!hg->lexicographic, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "-pc_hipgibbs_lexicographic is a one-rank option: on several ranks the sweep is multicoloured, as in the reference");
+  PetscCall(HipHostComm(PetscObjectComm((PetscObject)A), &hg->hc_comm, &hg->hc));
+  PetscCall(HipMPIAIJRows(A, &rp, &ci, &v, &starts, &hg->nowned));
+  PetscCall(HipCreateTransport(&hg->hc, NULL, &hg->transport));
+  /* colouring: the library's first-fit rule on the global matrix, computed rank after rank (the reference takes PETSc's
+     randomised JP colouring: any valid distance-1 colouring gives a valid Gibbs sampler) */
+  PMGCall(pmg_rowblock_sampler_create(&hg->hc, hg->transport, starts, rp, ci, v, 64, 0, NULL, hg->scaled ? hg->omega : 1.0, &hg->mc, &hg->dm));
+  PetscCall(PetscFree(rp));
+  PetscCall(PetscFree(ci));
+  PetscCall(PetscFree(v));
+  PetscCall(PetscFree(starts));
+  if (islrc) { /* B's rows are distributed like A's (a dense MPI matrix): hand over the local block */
+    Mat                Abase, Bmat;
+    Vec                S;
+    PetscInt           k, lda, mloc;
+    const PetscScalar *B, *Sarr;
+    double            *Bl;
+    int32_t            nlocal;
+
+    PetscCall(MatLRCGetMats(pc->pmat, &Abase, &Bmat, &S, NULL));
+    PetscCall(MatGetSize(Bmat, NULL, &k));
+    PetscCall(MatGetLocalSize(Bmat, &mloc, NULL));
+    PetscCheck(mloc == hg->nowned, PetscObjectComm((PetscObject)pc), PETSC_ERR_ARG_SIZ, "the rows of B must be distributed like the rows of A");
+    PetscCall(MatDenseGetLDA(Bmat, &lda));
+    PetscCall(MatDenseGetArrayRead(Bmat, &B));
+    PMGCall(pmg_mcsor_get_size(hg->mc, &nlocal)); /* owned rows + ghost rows */
+    PetscCall(PetscCalloc1((size_t)nlocal * (size_t)k, &Bl));
+    for (PetscInt c = 0; c < k; ++c) PetscCall(PetscArraycpy(Bl + (size_t)nlocal * c, B + (size_t)lda * c, mloc));
+    PetscCall(VecGetArrayRead(S, &Sarr)); /* S is replicated on every rank in the reference (src/woodbury.c:56-63 scatters all of it) */
+    PMGCall(pmg_distmcsor_set_lowrank(hg->dm, (int32_t)k, nlocal, (int32_t)hg->nowned, Bl, Sarr));
+    PetscCall(VecRestoreArrayRead(S, &Sarr));
+    PetscCall(MatDenseRestoreArrayRead(Bmat, &B));
+    PetscCall(PetscFree(Bl));
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 /* PCSetUp_SORGibbs / PCSetUp_MulticolorGibbs (reference src/pc_sorgibbs.c:181-260, src/pc_mcgibbs.c:213-255) */
 static PetscErrorCode PCSetUp_HipGibbs(PC pc)
 {
@@ -75,15 +138,24 @@ static PetscErrorCode PCSetUp_HipGibbs(PC pc)
   PetscMPIInt     size;
 
   PetscFunctionBeginUser;
-  PMGCall(pmg_mcsor_destroy(&hg->mc)); /* PCSetUp may run again on a new operator */
+  PMGCall(pmg_distmcsor_destroy(&hg->dm)); /* PCSetUp may run again on a new operator */
+  PMGCall(pmg_mcsor_destroy(&hg->mc));
+  if (hg->transport) PMGCall(pmg_dist_destroy_comm(&hg->hc, &hg->transport));
   PetscCall(PetscObjectTypeCompare((PetscObject)A, MATLRC, &islrc));
   if (islrc) PetscCall(MatLRCGetMats(pc->pmat, &A, NULL, NULL, NULL));
   PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)A), &size));
   PetscCall(PetscObjectTypeCompare((PetscObject)A, MATSEQAIJ, &isseq));
-  /* one rank = one device.  A MATMPIAIJ is swept by row blocks with one ghost update per colour (reference
-     src/mc_sor.c:298-381): that path is pmg_mcsor_create_csr_idx on the local rows + pmg_dist_* (INTEGRATION.md);
-     a DMDA operator split in z uses pmg_grid_create + pmg_dist_* */
-  PetscCheck(isseq || size == 1, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "Matrix type not supported by this constructor (MATSEQAIJ or MATLRC over it)");
+  PetscCall(HipNoiseSeed(hg->stream_id, &hg->seed));
+  if (size > 1) { /* one rank = one device: row blocks with one ghost update per colour (reference src/mc_sor.c:298-381) */
+    PetscCall(HipGibbsSetUpMPIAIJ(pc, A, islrc));
+    {
+      int32_t nc;
+      PMGCall(pmg_mcsor_get_num_colors(hg->mc, &nc));
+      hg->ncolors = nc - 1; /* the local operator keeps its ghost rows in one more colour that is never swept */
+    }
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  PetscCheck(isseq, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "Matrix type not supported (MATSEQAIJ, MATMPIAIJ, or MATLRC over one of them)");
   PetscCall(MatGetSize(A, &n, NULL));
   PetscCall(MatSeqAIJGetCSRAndMemType(A, &ia, &ja, &aa, NULL)); /* borrowed host arrays, as src/mc_sor.c:250 */
   PMGCall(pmg_mcsor_create_csr_idx((int64_t)n, ia, ja, aa, PMG_IDX_WIDTH, &hg->mc));
@@ -110,7 +182,6 @@ static PetscErrorCode PCSetUp_HipGibbs(PC pc)
     PMGCall(pmg_mcsor_get_num_colors(hg->mc, &nc));
     hg->ncolors = nc;
   }
-  PetscCall(HipNoiseSeed(&hg->seed));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -124,7 +195,13 @@ static PetscErrorCode HipGibbsSamples(PC pc, Vec b, Vec y, PetscInt its)
   PetscCall(PetscLogEventBegin(MULTICOL_SOR, pc, b, y, 0)); /* the reference logs every MCSORApply under this event, src/mc_sor.c:221 */
   PetscCall(HipVecGet(b, PETSC_FALSE, &hg->bbuf, &ab));
   PetscCall(HipVecGet(y, PETSC_TRUE, &hg->ybuf, &ay));
-  if (!hg->scb) {
+  if (hg->dm) { /* row block of a MATMPIAIJ: b and y are the local parts of the Vecs (natural order of the owned rows) */
+    const PetscInt chunk = hg->scb ? 1 : its;
+    for (PetscInt it = 0; it < its; it += chunk) {
+      PMGCall(pmg_distmcsor_sample(hg->dm, (int32_t)hg->nowned, ab.dev, ay.dev, (int32_t)chunk, (int)hg->scaled, (int)hg->type, hg->seed, hg->counter, &hg->counter, NULL));
+      if (hg->scb) PetscCall(HipCallSampleCallback(hg->scb, hg->cbctx, it, &ay, NULL)); /* src/pc_mcgibbs.c:183 */
+    }
+  } else if (!hg->scb) {
     PMGCall(pmg_mcsor_sample(hg->mc, ab.dev, ay.dev, (int32_t)its, (int)hg->scaled, hg->seed, hg->counter, &hg->counter, NULL));
   } else {
     for (PetscInt it = 0; it < its; ++it) {
@@ -259,9 +336,10 @@ static PetscErrorCode PCCreate_HipGibbsCommon(PC pc, PetscBool scaled)
 
   PetscFunctionBeginUser;
   PetscCall(PetscNew(&hg));
-  hg->scaled = scaled;
-  hg->omega  = 1;
-  hg->type   = SOR_FORWARD_SWEEP;
+  hg->scaled    = scaled;
+  hg->omega     = 1;
+  hg->type      = SOR_FORWARD_SWEEP;
+  hg->stream_id = ParMGMCHipNextStreamId(); /* PCs are created collectively, in the same order on every rank */
 
   pc->data                 = hg;
   pc->ops->setup           = PCSetUp_HipGibbs;
@@ -292,7 +370,7 @@ PetscErrorCode PCCreate_HipMulticolorGibbs(PC pc)
 /* ---- exact coarse sampler: PCCreate_CholSampler, dense path (reference src/pc_chols.c:174-194,262-342) ------------- */
 typedef struct {
   pmg_chol    ch;
-  uint64_t    seed, counter;
+  uint64_t    seed, counter, stream_id;
   HipStageBuf bbuf, ybuf;
   void *cbctx;
   PetscErrorCode (*scb)(PetscInt, Vec, void *);
@@ -325,7 +403,7 @@ static PetscErrorCode PCSetUp_HipChol(PC pc)
     PetscCall(MatDenseRestoreArrayRead(Bmat, &B));
     PetscCall(PetscFree(Bcopy));
   }
-  PetscCall(HipNoiseSeed(&hc->seed));
+  PetscCall(HipNoiseSeed(hc->stream_id, &hc->seed));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -422,6 +500,7 @@ PetscErrorCode PCCreate_HipCholSampler(PC pc)
 
   PetscFunctionBeginUser;
   PetscCall(PetscNew(&hc));
+  hc->stream_id            = ParMGMCHipNextStreamId();
   pc->data                 = hc;
   pc->ops->setup           = PCSetUp_HipChol;
   pc->ops->apply           = PCApply_HipChol;

@@ -126,6 +126,9 @@ pmg_status pmg_mcsor_residual_layout(pmg_mcsor mc, const double *b_lay, const do
    sweeps (parmgmc_amd/dist.py: DistMCSOR over torch.distributed).  row0 = global index of local row 0, so that the
    noise is that of the global row and the chain is the single-process chain bit for bit. */
 pmg_status pmg_mcsor_set_noise_row_offset(pmg_mcsor mc, int64_t row0);
+/* on != 0: idiag = omega / d in ONE rounding, PCPARSOR's rule (LocalMatInvertDiagonalForSOR, src/pc_parsor.c:53-86), instead
+   of MCSOR's (1/d) * omega (src/mc_sor.c:114-124).  Before set-up. */
+pmg_status pmg_mcsor_set_idiag_by_division(pmg_mcsor mc, int on);
 pmg_status pmg_mcsor_sweep_color_layout(pmg_mcsor mc, int32_t color, int noisy, int scaled, uint64_t seed, uint64_t sweep, const double *b_layout_dev, double *y_layout_dev, void *stream);
 /* MATLRC operators A + B S B^T (MCSORSetUp's LRC branch, src/mc_sor.c:572-595; MCSORBuildLRCCorrection :480-544):
    B is n x k column-major on the host in the matrix's row numbering, S the k diagonal entries of Sigma^-1.

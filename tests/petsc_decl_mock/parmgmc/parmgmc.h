@@ -6,6 +6,8 @@
 #define PCGAMGMC "gamgmc"
 #define PCSORGIBBS "sorgibbs"
 #define PCCHOLSAMPLER "cholsampler"
+#define PCPARSOR "parsor"
+#define PCWOODBURY "woodbury"
 PETSC_EXTERN PetscLogEvent  MULTICOL_SOR;
 PETSC_EXTERN PetscErrorCode PCRegisterSetSampleCallback(PC, PetscErrorCode (*)(PC, PetscErrorCode (*)(PetscInt, Vec, void *), void *, PetscErrorCode (*)(void *)));
 PETSC_EXTERN PetscErrorCode ParMGMCGetPetscRandom(PetscRandom *);

@@ -8,6 +8,7 @@
  */
 #ifndef PETSC_DECL_MOCK_H
 #define PETSC_DECL_MOCK_H
+#include <math.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -27,11 +28,22 @@ typedef enum { PETSC_FALSE, PETSC_TRUE } PetscBool;
 typedef int PetscLogEvent;
 typedef int PetscClassId;
 typedef int MPI_Comm;
+typedef int MPI_Datatype;
+typedef int MPI_Op;
+#define MPI_BYTE 1
+#define MPI_INT 2
+#define MPI_MIN 3
+#define MPI_SUCCESS 0
+typedef enum { DMDA_STENCIL_STAR, DMDA_STENCIL_BOX } DMDAStencilType;
+typedef enum { DM_BOUNDARY_NONE, DM_BOUNDARY_GHOSTED, DM_BOUNDARY_MIRROR, DM_BOUNDARY_PERIODIC } DMBoundaryType;
+#define PetscAbsReal(x) ((x) < 0 ? -(x) : (x))
+#define PetscSqrtReal(x) sqrt(x)
 typedef enum { PETSC_MEMTYPE_HOST = 0, PETSC_MEMTYPE_DEVICE = 1 } PetscMemType;
 #define PetscMemTypeHost(m) (((m) & 0x1) == PETSC_MEMTYPE_HOST)
 #define PetscMemTypeDevice(m) (((m) & 0x1) == PETSC_MEMTYPE_DEVICE)
 #define PETSC_SUCCESS 0
 #define PETSC_ERR_SUP 56
+#define PETSC_ERR_ARG_SIZ 60
 #define PETSC_ERR_GPU 97
 #define PETSC_COMM_SELF 1
 #define PETSC_EXTERN extern
@@ -50,6 +62,8 @@ typedef const char *PCType;
 typedef enum { SOR_FORWARD_SWEEP = 1, SOR_BACKWARD_SWEEP = 2, SOR_SYMMETRIC_SWEEP = 3, SOR_LOCAL_FORWARD_SWEEP = 4 } MatSORType;
 typedef enum { PCRICHARDSON_NOT_SET = 0, PCRICHARDSON_CONVERGED_RTOL = 2, PCRICHARDSON_CONVERGED_ATOL = 3, PCRICHARDSON_CONVERGED_ITS = 4 } PCRichardsonConvergedReason;
 #define MATSEQAIJ "seqaij"
+#define MATMPIAIJ "mpiaij"
+#define DMDA "da"
 #define MATLRC "lrc"
 #define PCMG "mg"
 #define PCGAMG "gamg"
@@ -82,6 +96,7 @@ PetscErrorCode PetscError(MPI_Comm, int, const char *, const char *, PetscErrorC
 #define PetscCheck(cond, comm, ierr, ...) do { if (!(cond)) return PetscError(comm, __LINE__, __func__, __FILE__, ierr, 0, __VA_ARGS__); } while (0)
 #define PetscNew(p) PetscMallocA_mock(sizeof(**(p)), (void **)(p))
 #define PetscMalloc1(n, p) PetscMallocA_mock((size_t)(n) * sizeof(**(p)), (void **)(p))
+#define PetscCalloc1(n, p) PetscMallocA_mock((size_t)(n) * sizeof(**(p)), (void **)(p))
 #define PetscFree(p) (PetscFree_mock((void *)(p)), (p) = NULL, PETSC_SUCCESS)
 #define PetscArraycpy(d, s, n) PetscMemcpy((d), (s), (size_t)(n) * sizeof(*(d)))
 PetscErrorCode PetscMallocA_mock(size_t, void **);
@@ -90,6 +105,10 @@ PetscErrorCode PetscMemcpy(void *, const void *, size_t);
 PetscErrorCode PetscStrncpy(char[], const char[], size_t);
 PetscErrorCode PetscSNPrintf(char *, size_t, const char[], ...);
 int            MPI_Comm_size(MPI_Comm, int *);
+int            MPI_Comm_rank(MPI_Comm, int *);
+int            MPI_Allgather(const void *, int, MPI_Datatype, void *, int, MPI_Datatype, MPI_Comm);
+int            MPI_Allreduce(const void *, void *, int, MPI_Datatype, MPI_Op, MPI_Comm);
+PetscErrorCode PetscObjectReference(PetscObject);
 MPI_Comm       PetscObjectComm(PetscObject);
 PetscErrorCode PetscObjectTypeCompare(PetscObject, const char[], PetscBool *);
 PetscErrorCode PetscObjectComposeFunction_Private(PetscObject, const char[], void (*)(void));
@@ -102,6 +121,8 @@ PetscErrorCode PetscLogEventEnd(PetscLogEvent, void *, void *, void *, void *);
 PetscErrorCode PetscOptionsBool(const char[], const char[], const char[], PetscBool, PetscBool *, PetscBool *);
 PetscErrorCode PetscOptionsRangeReal(const char[], const char[], const char[], PetscReal, PetscReal *, PetscBool *, PetscReal, PetscReal);
 PetscErrorCode PetscOptionsString(const char[], const char[], const char[], const char[], char[], size_t, PetscBool *);
+PetscErrorCode PetscOptionsReal(const char[], const char[], const char[], PetscReal, PetscReal *, PetscBool *);
+PetscErrorCode PetscOptionsInt(const char[], const char[], const char[], PetscInt, PetscInt *, PetscBool *);
 PetscErrorCode PetscOptionsHasName(PetscOptions, const char[], const char[], PetscBool *);
 PetscErrorCode PetscOptionsSetValue(PetscOptions, const char[], const char[]);
 PetscErrorCode PetscOptionsGetString(PetscOptions, const char[], const char[], char[], size_t, PetscBool *);
@@ -114,6 +135,7 @@ PetscErrorCode PetscRandomDestroy(PetscRandom *);
 /* Vec */
 PetscErrorCode VecGetLocalSize(Vec, PetscInt *);
 PetscErrorCode VecZeroEntries(Vec);
+PetscErrorCode VecDestroy(Vec *);
 PetscErrorCode VecGetArrayRead(Vec, const PetscScalar **);
 PetscErrorCode VecRestoreArrayRead(Vec, const PetscScalar **);
 PetscErrorCode VecGetArrayAndMemType(Vec, PetscScalar **, PetscMemType *);
@@ -127,12 +149,27 @@ PetscErrorCode MatLRCGetMats(Mat, Mat *, Mat *, Vec *, Mat *);
 PetscErrorCode MatDenseGetLDA(Mat, PetscInt *);
 PetscErrorCode MatDenseGetArrayRead(Mat, const PetscScalar **);
 PetscErrorCode MatDenseRestoreArrayRead(Mat, const PetscScalar **);
+PetscErrorCode MatDenseGetColumnVecRead(Mat, PetscInt, Vec *);
+PetscErrorCode MatDenseRestoreColumnVecRead(Mat, PetscInt, Vec *);
+PetscErrorCode MatCreateVecs(Mat, Vec *, Vec *);
+PetscErrorCode MatGetLocalSize(Mat, PetscInt *, PetscInt *);
+PetscErrorCode MatGetOwnershipRange(Mat, PetscInt *, PetscInt *);
+PetscErrorCode MatGetOwnershipRangeColumn(Mat, PetscInt *, PetscInt *);
+PetscErrorCode MatGetOwnershipRanges(Mat, const PetscInt **);
+PetscErrorCode MatMPIAIJGetSeqAIJ(Mat, Mat *, Mat *, const PetscInt *[]);
+PetscErrorCode MatGetRow(Mat, PetscInt, PetscInt *, const PetscInt *[], const PetscScalar *[]);
+PetscErrorCode MatRestoreRow(Mat, PetscInt, PetscInt *, const PetscInt *[], const PetscScalar *[]);
+/* DMDA */
+PetscErrorCode DMDAGetInfo(DM, PetscInt *, PetscInt *, PetscInt *, PetscInt *, PetscInt *, PetscInt *, PetscInt *, PetscInt *, PetscInt *, DMBoundaryType *, DMBoundaryType *, DMBoundaryType *, DMDAStencilType *);
+PetscErrorCode DMDAGetCorners(DM, PetscInt *, PetscInt *, PetscInt *, PetscInt *, PetscInt *, PetscInt *);
 /* PC / KSP / PCMG */
 PetscErrorCode PCCreate(MPI_Comm, PC *);
 PetscErrorCode PCDestroy(PC *);
 PetscErrorCode PCReset(PC);
 PetscErrorCode PCSetType(PC, PCType);
 PetscErrorCode PCSetUp(PC);
+PetscErrorCode PCApply(PC, Vec, Vec);
+PetscErrorCode PCApplyRichardson(PC, Vec, Vec, Vec, PetscReal, PetscReal, PetscReal, PetscInt, PetscBool, PetscInt *, PCRichardsonConvergedReason *);
 PetscErrorCode PCSetFromOptions(PC);
 PetscErrorCode PCView(PC, PetscViewer);
 PetscErrorCode PCSetDM(PC, DM);

@@ -1,5 +1,6 @@
 """The PETSc-side constructors (adapter/: PCCreate_HipSORGibbs, PCCreate_HipMulticolorGibbs, PCCreate_HipGAMGMC,
-PCCreate_HipCholSampler; they replace the constructors registered at reference src/parmgmc.c:44-54) cannot be built
+PCCreate_HipCholSampler, PCCreate_HipPARSOR, PCCreate_HipWoodbury -- all six type names the reference registers at
+src/parmgmc.c:44-54 -- each with its more-than-one-rank branch: MATMPIAIJ row blocks / DMDA z-slabs) cannot be built
 here: the image has no PETSc.  What CAN be checked without it:
   * the files are valid C, for 32- and 64-bit PetscInt, against a declaration-only transcription of the PETSc calls
     they make (tests/petsc_decl_mock: declarations, no definitions -- nothing links, nothing runs);
@@ -16,7 +17,7 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 ADAPTER = ROOT / "adapter"
-FILES = [ADAPTER / "pc_hipgibbs.c", ADAPTER / "pc_hipgamgmc.c"]
+FILES = [ADAPTER / "pc_hipgibbs.c", ADAPTER / "pc_hipgamgmc.c", ADAPTER / "pc_hipparsor.c", ADAPTER / "pc_hipwoodbury.c"]
 GCC = shutil.which("gcc")
 INC = ["-I", str(ROOT / "tests" / "petsc_decl_mock"), "-I", str(ROOT / "include"), "-I", "/opt/rocm/include", "-I", str(ADAPTER), "-D__HIP_PLATFORM_AMD__"]
 
@@ -54,8 +55,27 @@ def test_constructors_fill_the_ops_of_the_reference_constructors():
         assert f"pc->ops->{op}" in ctor, op
     assert "PCRegisterSetSampleCallback(pc, PCSetSampleCallback_HipGAMGMC)" in ctor and '"PCMGGetLevels_C"' in ctor
     reg = mg[mg.index("PetscErrorCode ParMGMCHipRegisterPCAll"):]
-    for name in ("PCSORGIBBS", "PCMCGIBBS", "PCGAMGMC", "PCCHOLSAMPLER"):
+    for name in ("PCSORGIBBS", "PCMCGIBBS", "PCGAMGMC", "PCCHOLSAMPLER", "PCPARSOR", "PCWOODBURY"):  # include/parmgmc/parmgmc.h:26-31
         assert f"PCRegister({name}," in reg
+    # the two constructors the round-2 adapter lacked: ops of reference src/pc_parsor.c:1021-1039 and src/woodbury.c:291-302
+    par = (ADAPTER / "pc_hipparsor.c").read_text()
+    ctor = par[par.index("PetscErrorCode PCCreate_HipPARSOR"):]
+    for op in ("apply", "destroy", "reset", "setup", "setfromoptions", "view"):
+        assert f"pc->ops->{op}" in ctor, op
+    assert "-pc_parsor_omega" in par and "-pc_parsor_its" in par and "pmg_mcsor_set_idiag_by_division" in par
+    wo = (ADAPTER / "pc_hipwoodbury.c").read_text()
+    ctor = wo[wo.index("PetscErrorCode PCCreate_HipWoodbury"):]
+    for op in ("setup", "reset", "destroy", "setfromoptions", "applyrichardson"):
+        assert f"pc->ops->{op}" in ctor, op
+    assert "PCRegisterSetSampleCallback(pc, PCSetSampleCallback_HipWoodbury)" in ctor
+    assert '"pc_woodbury_solver_"' in wo and '"pc_woodbury_sampler")' in wo and "-pc_woodbury_solver" in wo and "-pc_woodbury_sampler" in wo
+    # every constructor has its more-than-one-rank branch: no PETSC_ERR_SUP on size > 1 any more
+    assert "pmg_rowblock_sampler_create" in gibbs and "pmg_distmcsor_sample" in gibbs and "MatMPIAIJGetSeqAIJ" in (ADAPTER / "hip_petsc_common.h").read_text()
+    assert "pmg_mgmc_create_dmda_slab" in mg and "pmg_rbh_create_mgmc" in mg and "pmg_rbh_build" in mg
+    assert "pmg_distmcsor_apply" in par and "pmg_woodbury_correct" in wo and "pmg_dist_create_comm" in (ADAPTER / "hip_petsc_common.h").read_text()
+    # one noise stream per PC instance (reference: one advancing PetscRandom shared by all PCs, src/parmgmc.c:56-68)
+    for txt in (gibbs, mg, wo):
+        assert "ParMGMCHipNextStreamId()" in txt and "HipNoiseSeed(" in txt
     # option names of the reference
     for opt in ("-pc_mcgibbs_omega", "-pc_mcgibbs_forward", "-pc_mcgibbs_backward", "-pc_mcgibbs_symmetric", "-pc_sorgibbs_forward"):
         assert opt in gibbs
@@ -74,3 +94,4 @@ def test_adapter_calls_only_exported_c_abi_functions():
     assert all(hasattr(capi.lib, s) for s in used)
     # the index arrays cross the boundary with PetscInt's own width
     assert "pmg_mcsor_create_csr_idx" in used and "pmg_mgmc_set_level_operator_idx" in used and "pmg_chol_create_csr_idx" in used
+    assert "pmg_rowblock_merge_mpiaij" in used  # MatMPIAIJGetSeqAIJ's blocks cross with PetscInt's width too
