@@ -379,6 +379,31 @@ def test_plain_c_driver_on_the_c_abi():
             assert expect_view in r.stdout
 
 
+@pytest.mark.parametrize("pc_type,extra", [("mcgibbs", []), ("sorgibbs", []), ("gamgmc", ["-dist_levels", "3"])])
+def test_plain_c_driver_with_forked_ranks_reaches_the_multi_gpu_path(pc_type, extra, tmp_path):
+    """examples/pmg_bench -ranks N: no Python, no torch, no MPI in those processes.  The program forks its ranks before the
+    first HIP call, bootstraps the ipc halo transport with pmg_dist_create_comm over a byte all-gather made of pipes (the
+    pmg_host_comm callback a PETSc adapter fills with MPI_Allgather) and runs pmg_dist_sample_cvec /
+    pmg_mgmc_create_dmda_slab: the C-ABI alone reaches the multi-GPU path.  Noise is keyed on global indices, so 1, 2 and 3
+    ranks (sharing the one GPU of the box) must write the SAME BYTES."""
+    import subprocess
+    from pathlib import Path
+
+    exe = Path(__file__).resolve().parent.parent / "examples" / "pmg_bench"
+    assert exe.exists(), "build it with __graft_entry__.build()"
+    outs = {}
+    for ranks in (1, 2, 3):
+        pre = tmp_path / f"y{ranks}"
+        r = subprocess.run([str(exe), "-dim", "3", "-n", "33", "-pc_type", pc_type, *extra, "-ranks", str(ranks), "-share_device", "-n_burnin", "5", "-n_samples", "20", "-dump", str(pre)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"({ranks} ranks, ipc transport)" in r.stdout and "Time per sample [ms]" in r.stdout
+        outs[ranks] = b"".join((tmp_path / f"y{ranks}.{q}").read_bytes() for q in range(ranks))
+        assert len(outs[ranks]) == 8 * 33 ** 3
+    y = np.frombuffer(outs[1], np.float64)
+    assert np.isfinite(y).all() and abs(y.mean() - 0.01) < 0.005  # b = 1, kappa = 10: A^-1 b ~ 1/kappa^2
+    assert outs[2] == outs[1] and outs[3] == outs[1]
+
+
 def test_ex1_at_the_reference_budget():
     """reference examples/ex1.c:20 with ITS OWN budget and tolerance: 9x9 DMDA, kappa = 10, b = 1, -pc_type mcgibbs,
     burn-in 10^4 (ex1.c:119), 10^6 samples (ex1.c:126), relative error of the sample mean < 0.02 (ex1.c:133-135)."""
