@@ -245,6 +245,7 @@ _sig = {
     "pmg_dist_create_comm": (_int, [_vp, C.c_char_p, _vp, C.c_char_p, C.POINTER(_vp)]),
     "pmg_dist_destroy_comm": (_int, [_vp, C.POINTER(_vp)]),
     "pmg_mcsor_get_size": (_int, [_vp, C.POINTER(_i32)]),
+    "pmg_mcsor_set_idiag_by_division": (_int, [_vp, _int]),
     "pmg_distmcsor_sample": (_int, [_vp, _i32, _vp, _vp, _i32, _int, _int, _u64, _u64, C.POINTER(_u64), _vp]),
     "pmg_distmcsor_apply": (_int, [_vp, _i32, _vp, _vp, _int, _vp]),
     "pmg_woodbury_create": (_int, [_i64, _i32, _vp, _i64, _vp, _vp, C.POINTER(_vp)]),

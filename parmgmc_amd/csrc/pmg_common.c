@@ -1,5 +1,6 @@
 /* Error reporting, version strings and device-memory helpers of libparmgmc_hip. */
 #include "pmg_internal.h"
+#include <pthread.h>
 #include <dlfcn.h>
 #include <stdarg.h>
 
@@ -111,22 +112,28 @@ typedef int (*pmg_roctx_push_fn)(const char *);
 typedef int (*pmg_roctx_pop_fn)(void);
 static pmg_roctx_push_fn pmg_roctx_push;
 static pmg_roctx_pop_fn  pmg_roctx_pop;
-static int               pmg_trace_state; /* 0 = not probed, 1 = on, 2 = off */
+static int               pmg_trace_on; /* written once, inside pthread_once, after both function pointers */
+static pthread_once_t    pmg_trace_once = PTHREAD_ONCE_INIT;
 
+/* Runs exactly once per process, however many host threads enter the C-ABI together (the error buffer is thread-local, so
+   they may): pthread_once publishes the pointers and the flag to every thread that returns from it.  A range that one
+   thread pushes is popped by the same thread, and both see the same answer -- the round-2 code flipped a plain int through
+   "off" while it was still probing, so a second thread could skip a push and then pop. */
 static void pmg_trace_probe(void)
 {
   static const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
   const char        *env     = getenv("PMG_TRACE");
   const int          force   = env && env[0] == '1';
-  pmg_trace_state            = 2;
   if (env && env[0] == '0') return;
   for (unsigned q = 0; q < sizeof names / sizeof names[0]; ++q) {
     void *h = dlopen(names[q], RTLD_LAZY | (force ? 0 : RTLD_NOLOAD));
     if (!h) continue;
-    pmg_roctx_push = (pmg_roctx_push_fn)dlsym(h, "roctxRangePushA");
-    pmg_roctx_pop  = (pmg_roctx_pop_fn)dlsym(h, "roctxRangePop");
-    if (pmg_roctx_push && pmg_roctx_pop) {
-      pmg_trace_state = 1;
+    pmg_roctx_push_fn push = (pmg_roctx_push_fn)dlsym(h, "roctxRangePushA");
+    pmg_roctx_pop_fn  pop  = (pmg_roctx_pop_fn)dlsym(h, "roctxRangePop");
+    if (push && pop) {
+      pmg_roctx_push = push;
+      pmg_roctx_pop  = pop;
+      pmg_trace_on   = 1;
       return;
     }
   }
@@ -134,18 +141,19 @@ static void pmg_trace_probe(void)
 
 void pmg_trace_begin(const char *name)
 {
-  if (pmg_trace_state == 0) pmg_trace_probe();
-  if (pmg_trace_state == 1) (void)pmg_roctx_push(name);
+  pthread_once(&pmg_trace_once, pmg_trace_probe);
+  if (pmg_trace_on) (void)pmg_roctx_push(name);
 }
 
 void pmg_trace_end(void)
 {
-  if (pmg_trace_state == 1) (void)pmg_roctx_pop();
+  pthread_once(&pmg_trace_once, pmg_trace_probe);
+  if (pmg_trace_on) (void)pmg_roctx_pop();
 }
 
 /* 1 if ranges are being emitted (diagnostic for the tests) */
 int pmg_trace_enabled(void)
 {
-  if (pmg_trace_state == 0) pmg_trace_probe();
-  return pmg_trace_state == 1;
+  pthread_once(&pmg_trace_once, pmg_trace_probe);
+  return pmg_trace_on;
 }

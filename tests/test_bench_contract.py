@@ -24,9 +24,10 @@ def test_gpus_n_spawns_ranks_and_relays_their_failure_without_a_gpu():
     except Exception:
         have_gpu = False
     if not have_gpu:
-        # two child ranks were started by torch.distributed.run and each refused to run without a GPU
+        # child ranks were started by torch.distributed.run and refused to run without a GPU (the launcher ends the
+        # sibling as soon as the first rank has failed, so the second refusal is not always printed)
         assert r.returncode != 0
-        assert out.count("bench.py needs a GPU") >= 2, out[-2000:]
+        assert out.count("bench.py needs a GPU") >= 1, out[-2000:]
 
 
 def test_watchdog_reports_a_hang_with_a_nonzero_exit_code():
