@@ -19,7 +19,10 @@ class PMGError(RuntimeError):
 
 
 def library_path() -> Path:
-    return _PKG / "libparmgmc_hip.so"
+    import os
+
+    alt = os.environ.get("PMG_LIBRARY")  # development: an A/B build of the library (tools/ab_build.sh)
+    return Path(alt) if alt else _PKG / "libparmgmc_hip.so"
 
 
 def header_path() -> Path:

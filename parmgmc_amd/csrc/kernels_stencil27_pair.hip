@@ -100,8 +100,8 @@ struct pair_ctx {
 // values the FIRST point sees.  The rows are consumed as a stream, in the order of the sum: the first point takes all
 // of them; the second point's terms of the rows before its own line (0..3) are accumulated in the same pass, its own
 // line (row 4) needs the first colour's new values on both sides -- own register and the neighbouring lane's, one
-// wave shuffle -- and the rows behind it (5..8) are kept (12 values) until then.  Keeping all 36 values of the
-// neighbourhood instead costs 130 VGPRs and two fifths of the occupancy.
+// wave shuffle -- and the rows behind it (5..8) are fetched again at that point (round 3; round 2 kept their 12 values in
+// registers: 78 VGPRs).  Keeping all 36 values of the neighbourhood costs 130 VGPRs and two fifths of the occupancy.
 template <bool NOISY, bool FIRST1, class RowFn, class ZeroFn>
 __device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, ZeroFn &&row_is_zero, const double *s_coef, const double *s_idiag, const double *s_sqrtd, const pmg::LogTabEntry *s_logtab, d2 bb)
 {
@@ -129,16 +129,12 @@ __device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, Zer
   }
   const double *cfF = s_coef + 27 * clsF, *cfS = s_coef + 27 * clsS;
   double        accF = F ? w1 : w0, accS = S ? w1 : w0;
-  double        oldF = 0.0, oldS = 0.0, keep[4][3];
+  double        oldF = 0.0, oldS = 0.0;
 #pragma unroll
   for (int row = 0; row < 9; ++row) {
     // a row known to hold zeros (first sweep from a zero guess): its terms are skipped altogether -- they would subtract
     // +-0 -- and nothing is loaded; after unrolling the test is a compile-time constant
-    if (row_is_zero(row)) {
-      if (row > 4)
-        for (int q = 0; q < 3; ++q) keep[row - 5][q] = 0.0;
-      continue;
-    }
+    if (row_is_zero(row)) continue;
     double r[4];
     get_row(row, r);
 #pragma unroll
@@ -152,9 +148,6 @@ __device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, Zer
     } else if (row == 4) {
       oldF = r[1 + F];
       oldS = r[1 + S];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) keep[row - 5][q] = r[S + q];
     }
   }
   double nF = C.om1 * oldF + s_idiag[clsF] * accF;
@@ -167,8 +160,10 @@ __device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, Zer
 #pragma unroll
   for (int row = 5; row < 9; ++row) {
     if (row_is_zero(row)) continue;
+    double r[4]; // fetched a SECOND time (L1 hit in stage A, register / LDS copy in stage B) instead of twelve values carried
+    get_row(row, r); // over the first point's sum: 78 -> 72 VGPRs, 6 -> 7 waves per SIMD, 257^3 level sweep -3 %
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) accS = accS - cfS[3 * row + dx + 1] * keep[row - 5][dx + 1];
+    for (int dx = -1; dx <= 1; ++dx) accS = accS - cfS[3 * row + dx + 1] * r[S + dx + 1];
   }
   double nS = C.om1 * oldS + s_idiag[clsS] * accS;
   nS        = (S ? C.act1 : C.act0) ? nS : 0.0;
