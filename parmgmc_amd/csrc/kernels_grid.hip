@@ -472,12 +472,18 @@ __device__ __forceinline__ rr_line rr_load_line(const rr_plane &pl, uint32_t lin
 // L, C: fine layout and coarse extents of this rank (a single device: kz0 = 0, nz = nzg, ylo2 = yhi2 = NULL).  A z-slab
 // restricts into the coarse planes it owns (K with fine plane 2K on this rank): it needs the residual on its two ghost
 // planes, i.e. y two planes deep (ylo2, yhi2) and b on the ghost planes.
+template <bool SYNC>
 __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_layout L, pmgk_grid_op op, pmgk_st27_dims C, int tplE, int wpp, int kc, int nchunks, const double *__restrict__ b, const double *__restrict__ y, const double *__restrict__ ylo2, const double *__restrict__ yhi2, double *__restrict__ bc)
 {
   const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3, per = (int)gridDim.x >> 3;
   const int gw  = __builtin_amdgcn_readfirstlane((xcd * per + q) * 4 + (int)(threadIdx.x >> 6));
-  const int zc = gw / wpp, wv = gw - zc * wpp;
-  if (zc >= nchunks) return; // whole wavefront
+  // SYNC: the wavefronts of a chunk are counted in whole workgroups (wppb = wpp rounded up to 4), so that the four wavefronts
+  // of a workgroup -- neighbours in the (coarse line, x) list, which read each other's fine lines -- belong to ONE chunk, make
+  // the same number of plane steps and can meet at a barrier per step (the spare wavefronts of a chunk repeat its last slots
+  // without storing)
+  const int wppb = SYNC ? (wpp + 3) / 4 * 4 : wpp;
+  const int zc = gw / wppb, wv = gw - zc * wppb;
+  if (zc >= nchunks) return; // whole wavefront (SYNC: whole workgroup)
   const int  lane = threadIdx.x & 63, nslots = C.ny * tplE;
   const int  fu = 62 * wv + lane - 1, f = min(max(fu, 0), nslots - 1);
   const bool store = lane >= 1 && lane <= 62 && fu < nslots;
@@ -523,6 +529,12 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
     hN = rr_load_line(pc, (uint32_t)jN * sx8 + T.lo, (jN + kfirst) & 1);
   }
   for (int k = kfirst; k <= klast; ++k) {
+    // one barrier per plane step keeps the four wavefronts of a workgroup on the same plane: the two lines beside a
+    // wavefront's three and the line it shares with its neighbour are then requested by both within one step and the second
+    // request finds them in the CU's L1 / the XCD's L2 instead of fetching them again over the fabric (all resident
+    // wavefronts of an XCD together touch more than its L2 holds per step, so without the barrier a drifting neighbour's
+    // line is gone before it is needed)
+    if (SYNC) __syncthreads();
     int J = Jc; // per plane: what depends on the lines alone would otherwise be kept in registers across the march
     asm volatile("" : "+v"(J));
     const bool     hasD = k > 0, hasU = k < L.nzg - 1, odd = k & 1; // wave-uniform
@@ -743,12 +755,21 @@ extern "C" int pmgk_grid_residual_restrict(const pmgk_grid_layout *L, const pmgk
   static const int kc_env = getenv("PMG_GRID_RR_CHUNK") ? atoi(getenv("PMG_GRID_RR_CHUNK")) : 0;
   if (!pmgk_grid_residual_restrict_applies(L, C, ylo2 != nullptr, yhi2 != nullptr)) return -1;
   const int     tplE = grid_threads_per_line(L);
+  // one barrier per plane step (see the kernel): -3 % time and fabric reads at 513^3 and 257^3, +5 % on grids of a few
+  // microseconds, where the wavefronts barely drift (tools/rrbench.py, tools/pmc_one.sh; PMG_GRID_RR_SYNC = 0 | 1 forces)
+  static const int sync_knob = getenv("PMG_GRID_RR_SYNC") ? atoi(getenv("PMG_GRID_RR_SYNC")) : -1;
+  const int        sync_env  = sync_knob >= 0 ? sync_knob : ((int64_t)L->nx * L->ny * L->nz >= 8000000);
   const int     wpp = (int)(((int64_t)C->ny * tplE + 61) / 62);
   int           kc  = kc_env > 0 ? kc_env : 8; // coarse planes per chunk: each chunk re-reads one fine plane
   while (kc_env <= 0 && kc > 2 && (int64_t)wpp * ((C->nz + kc - 1) / kc) < 2048) kc >>= 1;
   const int     nchunks = (C->nz + kc - 1) / kc;
-  const int64_t nblocks = ((int64_t)wpp * nchunks + 3) / 4;
-  hipLaunchKernelGGL(grid_residual_restrict_kernel, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, *L, *op, *C, tplE, wpp, kc, nchunks, b, y, ylo2, yhi2, bc);
+  if (sync_env) {
+    const int64_t nblocks = (int64_t)((wpp + 3) / 4) * nchunks;
+    hipLaunchKernelGGL(grid_residual_restrict_kernel<true>, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, *L, *op, *C, tplE, wpp, kc, nchunks, b, y, ylo2, yhi2, bc);
+  } else {
+    const int64_t nblocks = ((int64_t)wpp * nchunks + 3) / 4;
+    hipLaunchKernelGGL(grid_residual_restrict_kernel<false>, dim3((unsigned)((nblocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, *L, *op, *C, tplE, wpp, kc, nchunks, b, y, ylo2, yhi2, bc);
+  }
   return launch_status();
 }
 
