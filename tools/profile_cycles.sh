@@ -5,7 +5,7 @@ set -e
 tag=$1; shift
 keys=${@:-"mgmc_257_5 mgmc_513_6 mgmc_lowrank_257_5_k3 sell_sweep_377089 sell_sweep_1505793 mgmc_aij_377089"}
 root=$GRAFT_REPO_ROOT
-out=$root/gpurun_out/$tag
+out=$root/gpurun_out/${tag}_cycles
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 S=5
