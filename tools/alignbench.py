@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""What costs the padded 2^k+1 layouts their 13-15 %?  512^3 sweep (ns per 1000 point updates) with the lines kept
-contiguous inside a plane but the PLANES shifted off their natural alignment (PMG_GRID_SP_PAD doubles behind every plane),
-against padded lines (PMG_GRID_SX_ALIGN cannot pad 256; the padded-line number is 513^3's).  Development tool."""
+"""What costs the 2^k+1 grids their 15-17 % per point against 2^k?  The noisy sweep (ns per 1000 point updates) on boxes that
+are odd in one direction at a time; PMG_GRID_SP_PAD=<doubles> (read by pmg_grid_create) shifts the planes of any grid off
+their natural alignment.  Development tool; results in DESIGN.md section 9, item 5."""
 import os
 import sys
 from pathlib import Path
@@ -12,8 +12,8 @@ import torch
 from parmgmc_amd import GridMCSOR
 
 
-def run(n, reps=60):
-    g = GridMCSOR(n, n, n, 10.0)
+def run(nx, ny, nz, reps=60):
+    g = GridMCSOR(nx, ny, nz, 10.0)
     b = g.to_cvec(torch.ones(g.n, dtype=torch.float64, device="cuda"))
     y = g.new_cvec()
     c = g.sample_cvec(b, y, 150, 0xCAFE, 0, True)
@@ -22,10 +22,9 @@ def run(n, reps=60):
     g.sample_cvec(b, y, reps, 0xCAFE, c, True)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e9 / n ** 3
+    return e0.elapsed_time(e1) / reps * 1e9 / (nx * ny * nz)
 
 
-for rep in range(3):
-    for n, pad in ((512, 0), (512, 16), (512, 32), (512, 64), (512, 256), (512, 2048), (513, 0), (513, 48), (513, 240)):
-        os.environ["PMG_GRID_SP_PAD"] = str(pad)
-        print(f"rep {rep} n={n} sp_pad={pad:5d}: {run(n):.3f} ns/kpt", flush=True)
+for rep in range(2):
+    for dims in ((512, 512, 512), (513, 512, 512), (512, 513, 512), (512, 512, 513), (512, 516, 512), (512, 520, 512), (512, 544, 512), (513, 513, 513), (512, 513, 513)):
+        print(f"rep {rep} {dims}: {run(*dims):.3f} ns/kpt", flush=True)
