@@ -40,6 +40,113 @@ int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, 
   return 1;
 }
 
+/* ---- pmg_rowblock.c (the multi-rank set-up in C) is host code apart from its last two entry points: it runs here on THREE
+   ranks = three threads whose byte all-gather is a shared buffer between two barriers.  The device-side functions it can
+   call (sampler / transport creation) are not part of this program: stubs that fail if reached. ------------------------ */
+#include <pthread.h>
+#define STUB(name, ...) pmg_status name(__VA_ARGS__) { return PMG_ERR_SUP; }
+typedef struct pmg_mcsor_s     *san_mc;
+typedef struct pmg_distmcsor_s *san_dm;
+STUB(pmg_mcsor_create_csr, int32_t n, const int32_t *a, const int32_t *b, const double *c, pmg_mcsor *o) 
+STUB(pmg_mcsor_set_coloring, pmg_mcsor m, int r, const int32_t *c)
+STUB(pmg_mcsor_set_omega, pmg_mcsor m, double o)
+STUB(pmg_mcsor_setup, pmg_mcsor m)
+STUB(pmg_mcsor_set_noise_row_offset, pmg_mcsor m, int64_t r)
+STUB(pmg_mcsor_get_layout, pmg_mcsor m, int32_t *p)
+STUB(pmg_mcsor_destroy, pmg_mcsor *m)
+void pmg_mcsor_adopt_arrays(pmg_mcsor m, int32_t *a, int32_t *b, double *c) { (void)m; (void)a; (void)b; (void)c; }
+STUB(pmg_distmcsor_create, pmg_mcsor m, pmg_dist d, int32_t nc, const int64_t *a, const int32_t *b, const int64_t *c, const int64_t *e, const int32_t *f, const int32_t *g, pmg_distmcsor *o)
+STUB(pmg_distmcsor_destroy, pmg_distmcsor *h)
+STUB(pmg_dist_get_unique_id, const char *p, void *id)
+STUB(pmg_dist_create, pmg_grid g, int32_t r, int32_t n, const void *id, const char *p, int l, pmg_dist *d)
+STUB(pmg_dist_create_ipc, pmg_grid g, int32_t r, int32_t n, pmg_dist *d)
+STUB(pmg_dist_ipc_blob_bytes, int32_t *b)
+STUB(pmg_dist_ipc_export, pmg_dist d, void *b)
+STUB(pmg_dist_ipc_connect, pmg_dist d, const void *a, const void *b)
+STUB(pmg_dist_ipc_connect_all, pmg_dist d, const void *const *b)
+STUB(pmg_dist_ipc_disconnect, pmg_dist d)
+STUB(pmg_dist_destroy, pmg_dist *d)
+STUB(pmg_mgmc_create_hierarchy, int32_t l, pmg_mgmc *m)
+STUB(pmg_mgmc_set_level_operator, pmg_mgmc m, int32_t l, int32_t n, const int32_t *a, const int32_t *b, const double *c)
+STUB(pmg_mgmc_set_level_interpolation, pmg_mgmc m, int32_t l, int32_t n, int32_t k, const int32_t *a, const int32_t *b, const double *c)
+STUB(pmg_mgmc_set_rowblock_transport, pmg_mgmc m, pmg_dist d, const int64_t *c)
+STUB(pmg_mgmc_set_level_rowblock, pmg_mgmc m, int32_t l, int64_t r0, int32_t no, int32_t nc, const int32_t *c, const int64_t *a, const int32_t *b, const int64_t *d, const int64_t *e, const int32_t *f, const int32_t *g)
+STUB(pmg_mgmc_set_level_restriction, pmg_mgmc m, int32_t l, int32_t n, int32_t k, const int32_t *a, const int32_t *b, const double *c)
+STUB(pmg_mgmc_destroy, pmg_mgmc *m)
+
+#define SAN_RANKS 3
+static pthread_barrier_t san_bar;
+static char              san_buf[1 << 20];
+static int san_allgather(void *ctx, const void *send, int64_t nbytes, void *recv)
+{
+  const int rank = *(const int *)ctx;
+  if (nbytes * SAN_RANKS > (int64_t)sizeof san_buf) return 1;
+  if (nbytes) memcpy(san_buf + (size_t)nbytes * (size_t)rank, send, (size_t)nbytes);
+  pthread_barrier_wait(&san_bar);
+  if (nbytes) memcpy(recv, san_buf, (size_t)nbytes * SAN_RANKS);
+  pthread_barrier_wait(&san_bar);
+  return 0;
+}
+
+/* a 3-level hierarchy of chains: level 2 = 1-D Laplacian on n2 points with a few long-range couplings (so that ghost rows
+   are not only the neighbours of the block edges), level l-1 = pairs aggregated; every rank holds its rows */
+static void *san_rank(void *arg)
+{
+  const int     rank = *(int *)arg;
+  int           rk   = rank;
+  pmg_host_comm hc   = {rank, SAN_RANKS, san_allgather, &rk};
+  const int64_t n[3] = {35, 70, 140};
+  intptr_t      fail = 0;
+  pmg_rbh       h    = NULL;
+  if (pmg_rbh_create(&hc, 3, 40, &h)) return (void *)1;
+  for (int l = 0; l < 3 && !fail; ++l) {
+    const int64_t r0 = n[l] * rank / SAN_RANKS, r1 = n[l] * (rank + 1) / SAN_RANKS, nl = r1 - r0;
+    int64_t      *rp = malloc(sizeof(int64_t) * (size_t)(nl + 1)), *ci = malloc(sizeof(int64_t) * (size_t)(5 * nl));
+    double       *v  = malloc(sizeof(double) * (size_t)(5 * nl));
+    int64_t       q  = 0;
+    rp[0] = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t far = (r * 7 + 3) % n[l];
+      const int64_t cand[5] = {r - 1, r, r + 1, far, (n[l] - 1 - far)};
+      for (int c = 0; c < 5; ++c) {
+        int dup = cand[c] < 0 || cand[c] >= n[l];
+        for (int d = 0; d < c && !dup; ++d) dup = cand[d] == cand[c];
+        /* structural symmetry is not needed by the plan builders; the colouring sees each row's own list */
+        if (!dup) ci[q] = cand[c], v[q] = cand[c] == r ? 4.0 : -0.5, ++q;
+      }
+      rp[r - r0 + 1] = q;
+    }
+    if (pmg_rbh_set_level_operator(h, l, n[l], r0, nl, rp, ci, v, 64)) fail = 2;
+    free(rp), free(ci), free(v);
+    if (l >= 1 && !fail) { /* P_l: fine row r -> coarse r / 2 */
+      int32_t *prp = malloc(sizeof(int32_t) * (size_t)(nl + 1)), *pci = malloc(sizeof(int32_t) * (size_t)(nl > 0 ? nl : 1));
+      double  *pv  = malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1));
+      for (int64_t r = 0; r <= nl; ++r) prp[r] = (int32_t)r;
+      for (int64_t r = 0; r < nl; ++r) pci[r] = (int32_t)((r0 + r) / 2), pv[r] = 1.0;
+      if (pmg_rbh_set_level_interpolation(h, l, nl, prp, pci, pv, 32)) fail = 3;
+      free(prp), free(pci), free(pv);
+    }
+  }
+  if (!fail && pmg_rbh_build(h)) fail = 4;
+  int32_t nl = 0, fold = 0;
+  if (!fail && (pmg_rbh_get_info(h, &nl, &fold) || nl != 3 || fold != 1)) fail = 5;
+  for (int l = 0; l < 3 && !fail; ++l) {
+    pmg_rbh_level_view vw;
+    if (pmg_rbh_get_level(h, l, &vw)) fail = 6;
+    else if (!vw.replicated) { /* every local index inside the local matrix, every ghost refreshed exactly once */
+      for (int32_t k = 0; k < vw.rp[vw.nlocal] && !fail; ++k)
+        if (vw.ci[k] < 0 || vw.ci[k] >= vw.nlocal) fail = 7;
+      for (int32_t k = 0; k < vw.R_rp[vw.R_nrows] && !fail; ++k)
+        if (vw.R_ci[k] < 0 || vw.R_ci[k] >= vw.nlocal) fail = 8;
+      if (vw.recv_ptr[vw.ncolors] != vw.nghost) fail = 9;
+    } else if (vw.nlocal != n[l]) fail = 10;
+  }
+  pmg_mgmc mg = NULL;
+  if (!fail && pmg_rbh_create_mgmc(h, (pmg_dist)&hc, &mg) != PMG_ERR_SUP) fail = 11; /* reaches the (stubbed) device layer and unwinds */
+  pmg_rbh_destroy(&h);
+  return (void *)fail;
+}
+
 #define REQUIRE(c) \
   do { \
     if (!(c)) { \
@@ -143,6 +250,32 @@ int main(void)
   free(ecol);
   free(cls);
   free(rp); free(ci); free(dp); free(v); free(idg); free(sd); free(b); free(y); free(y0); free(w); free(xi); free(crow); free(rows); free(out);
+  /* ---- pmg_rowblock.c on three ranks (threads) ---- */
+  {
+    pthread_t th[SAN_RANKS];
+    int       ids[SAN_RANKS];
+    REQUIRE(pthread_barrier_init(&san_bar, NULL, SAN_RANKS) == 0);
+    for (int r = 0; r < SAN_RANKS; ++r) {
+      ids[r] = r;
+      REQUIRE(pthread_create(&th[r], NULL, san_rank, &ids[r]) == 0);
+    }
+    for (int r = 0; r < SAN_RANKS; ++r) {
+      void *ret = NULL;
+      REQUIRE(pthread_join(th[r], &ret) == 0);
+      if (ret) fprintf(stderr, "host_san: row-block rank %d failed at step %ld: %s\n", r, (long)(intptr_t)ret, pmg_last_error_string());
+      REQUIRE(ret == NULL);
+    }
+    /* MatMPIAIJGetSeqAIJ's blocks -> rows, both orders, 32-bit indices */
+    const int32_t ad_rp[3] = {0, 2, 4}, ad_ci[4] = {0, 1, 0, 1}, ao_rp[3] = {0, 1, 3}, ao_ci[3] = {1, 0, 2}, ga[3] = {0, 1, 6};
+    const double  ad_v[4] = {4, -1, -1, 4}, ao_v[3] = {-2, -3, -5};
+    int64_t       mrp[3], mci[7];
+    double        mv[7];
+    REQUIRE(pmg_rowblock_merge_mpiaij(2, 3, ad_rp, ad_ci, ad_v, ao_rp, ao_ci, ao_v, ga, 32, PMG_ROWBLOCK_ORDER_GLOBAL, mrp, mci, mv) == 0);
+    REQUIRE(mrp[2] == 7 && mci[0] == 1 && mci[1] == 3 && mci[2] == 4 && mci[3] == 0 && mci[6] == 6 && mv[3] == -3 && mv[6] == -5);
+    REQUIRE(pmg_rowblock_merge_mpiaij(2, 3, ad_rp, ad_ci, ad_v, ao_rp, ao_ci, ao_v, ga, 32, PMG_ROWBLOCK_ORDER_MPIAIJ, mrp, mci, mv) == 0);
+    REQUIRE(mci[0] == 3 && mci[2] == 1 && mci[3] == 3 && mci[5] == 0 && mci[6] == 6);
+    REQUIRE(pmg_rowblock_merge_mpiaij(2, 3, ad_rp, ad_ci, ad_v, ao_rp, ao_ci, ao_v, ga, 48, 0, mrp, mci, mv) == PMG_ERR_ARG_OUTOFRANGE);
+  }
   printf("host_san ok\n");
   return 0;
 }

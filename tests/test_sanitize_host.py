@@ -16,8 +16,8 @@ def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
         pytest.skip("no gcc")
     exe = tmp_path / "host_san"
     csrc = ROOT / "parmgmc_amd" / "csrc"
-    srcs = [ROOT / "tests" / "sanitize" / "host_san.c", ROOT / "oracle" / "pmg_oracle.c", csrc / "pmg_common.c", csrc / "pmg_diag.c", csrc / "pmg_parsor.c"]
-    cmd = [gcc, "-std=gnu11", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", str(ROOT / "include"), *map(str, srcs), "-o", str(exe), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-ldl"]
+    srcs = [ROOT / "tests" / "sanitize" / "host_san.c", ROOT / "oracle" / "pmg_oracle.c", csrc / "pmg_common.c", csrc / "pmg_diag.c", csrc / "pmg_parsor.c", csrc / "pmg_rowblock.c"]
+    cmd = [gcc, "-std=gnu11", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", str(ROOT / "include"), *map(str, srcs), "-o", str(exe), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-ldl", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "cannot find" in r.stderr:
         pytest.skip("sanitizer runtime not installed")
