@@ -237,14 +237,27 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
   int                         t, j;
   if (TAIL && (int)blockIdx.z >= kcount) {
     const int tb  = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * ((int)blockIdx.z - kcount));
-    const int per = (L.ny * tailw + 255) / 256; // tail blocks per plane
-    const int kz = tb / per, part = tb - kz * per;
+    // On the multigrid sizes nx = 4 tmain + 1 the one tail thread of a line owns the point i = nx - 1 alone, and that point
+    // has this colour only on the lines with (c + j + k) even: the tails of those lines are collected (every lane of a tail
+    // block busy) instead of one thread per line, half of which would leave at once.  Measured on one box against the
+    // one-thread-per-line form (tools/alignbench.py, A/B builds): 257^3 5.74 -> 5.56 ns per 1000 points, but 513^3 5.64 -> 5.78
+    // -- so only where the lines are packed tightly (the Infinity-Cache regime of pmg_grid_line_stride), whose tails share
+    // cache lines with the next line's head
+    const bool compact = tailw == 1 && L.nx == 4 * tmain + 1 && (L.sx & 15) != 0;
+    const int  slots   = compact ? (L.ny + 1) / 2 : L.ny * tailw;
+    const int  per     = (slots + 255) / 256; // tail blocks per plane
+    const int  kz = tb / per, part = tb - kz * per;
     if (kz >= kcount) return;
     if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x);
-    const int f = (part * 4 + ty) * 64 + (int)threadIdx.x;
-    j           = f / tailw;
-    t           = tmain + f - j * tailw;
-    grid_color_sweep_body<NOISY, OMEGA1, false, true>(L, op, c, t, j, kbegin + kz * kstride, tab, halo, b_own, y_other, y_own);
+    const int f = (part * 4 + ty) * 64 + (int)threadIdx.x, kt = kbegin + kz * kstride;
+    if (compact) {
+      j = 2 * f + ((c + kt + L.kz0) & 1);
+      t = tmain;
+    } else {
+      j = f / tailw;
+      t = tmain + f - j * tailw;
+    }
+    grid_color_sweep_body<NOISY, OMEGA1, false, true>(L, op, c, t, j, kt, tab, halo, b_own, y_other, y_own);
     return;
   }
   if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x); // (gathering from the global table instead: 0.60 vs 0.62)
