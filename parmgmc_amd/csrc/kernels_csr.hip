@@ -13,6 +13,7 @@
 // row itself.  Vectors handled here are in the permuted numbering.
 #include <hip/hip_runtime.h>
 #include "pmg_kernels.h"
+#define PMG_RNG_TU csr
 #include "pmg_rng.hpp"
 
 namespace {

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <stdlib.h>
 #include "pmg_kernels.h"
+#define PMG_RNG_TU grid
 #include "pmg_rng.hpp"
 
 namespace {
@@ -117,13 +118,21 @@ __device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, un
 }
 
 template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED>
-__device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L, const pmgk_grid_op &op, int c, int t, int j, int k, const pmg::LogTabEntry *tab, const pmgk_grid_halo &halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+__device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L, const pmgk_grid_op &op, int c, int t, int j, int k, pmg::LogTabEntry *tab, pmg::LogTabEntry tab_entry, const pmgk_grid_halo &halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
 {
-  if (j >= L.ny || 2 * t >= L.sx) return;
   const int kg = k + L.kz0;
+  // NOISY: lane i of the wavefront carries entry i of the log table (requested by the caller, still in flight) into the
+  // wavefront's LDS copy inside normal_pair_fill, so every lane must stay until then: a lane without a point moves to
+  // (t, j) = (0, 0) -- valid addresses -- and only its stores are suppressed
+  bool live = j < L.ny && 2 * t < L.sx && 4 * t + ((c + j + kg) & 1) < L.nx;
+  if (NOISY) {
+    if (!__builtin_amdgcn_ballot_w64(live)) return;
+    t = live ? t : 0;
+    if (PACKED) j = live ? j : 0;
+  } else if (!live)
+    return;
   const int p  = (c + j + kg) & 1;
   const int i0 = 4 * t + p, i1 = i0 + 2; // grid columns of the two points
-  if (i0 >= L.nx) return;
   const bool v1 = i1 < L.nx;
 
   const bool    hasS = j > 0, hasN = j < L.ny - 1, hasD = kg > 0, hasU = kg < L.nzg - 1;
@@ -137,31 +146,51 @@ __device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L,
   // p=0: left(0)=m' 2t-1 (ed), right(0)=2t,   left(1)=2t,   right(1)=2t+1
   // p=1: left(0)=m' 2t,        right(0)=2t+1, left(1)=2t+1, right(1)=2t+2 (ed)
   const int    eo = p ? (2 * t + 2 < L.sx ? 2 : 1) : (t > 0 ? -1 : 0); // clamped lane-neighbour offset
-  const d2     Vc = ld2(at_bytes(yo_row, lo));
-  const double ed = *at_bytes(yo_row, lo + 8u * (uint32_t)eo);
-  const d2     oS = ld2(at_bytes(yo_row - (hasS ? L.sx : 0), lo));
-  const d2     oN = ld2(at_bytes(yo_row + (hasN ? L.sx : 0), lo));
-  const int64_t inplane = (int64_t)j * L.sx + 2 * t; // offset inside one plane
-  const d2      oD = (HALO && k == 0 && halo.glo) ? ld2_sys(halo.glo + inplane) : ld2(at_bytes(yo_row - (hasD ? L.sp : 0), lo));
-  const d2      oU = (HALO && k == L.nz - 1 && halo.ghi) ? ld2_sys(halo.ghi + inplane) : ld2(at_bytes(yo_row + (hasU ? L.sp : 0), lo));
-  const d2     bb = ld2(at_bytes(b_own + rowoff, lo));
-
-  const double L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
   const bool   hasW0 = i0 > 0, hasE0 = i0 < L.nx - 1, hasE1 = i1 < L.nx - 1;
   // diagonal-dependent constants: the point has nyz in-domain y/z neighbours (wave-uniform) plus 1 or 2 in x
   // min(distance to the face, 1): integer arithmetic keeps the wave-uniform count on the scalar unit (summing the four
-  // booleans goes through v_cndmask 0/1)
+  // booleans goes through v_cndmask 0/1).  Fetched here, in front of the streaming loads (scalar loads of the operator
+  // table: behind the loads they would be waited for a second time)
   const int    nyz = PACKED ? (int)hasS + (int)hasN + (int)hasD + (int)hasU : min(j, 1) + min(L.ny - 1 - j, 1) + min(kg, 1) + min(L.nzg - 1 - kg, 1);
   const bool   two0 = hasW0 && hasE0, two1 = hasE1;
   const double idA = table_at<PACKED>(op.idiag, nyz + 1), idB = table_at<PACKED>(op.idiag, nyz + 2);
+  const double sqA = NOISY ? table_at<PACKED>(op.sqrtdiag, nyz + 1) : 0.0, sqB = NOISY ? table_at<PACKED>(op.sqrtdiag, nyz + 2) : 0.0;
+  double      *out_row = y_own + rowoff;
+  d2     Vc = ld2(at_bytes(yo_row, lo));
+  double ed = *at_bytes(yo_row, lo + 8u * (uint32_t)eo);
+  d2     oS = ld2(at_bytes(yo_row - (hasS ? L.sx : 0), lo));
+  d2     oN = ld2(at_bytes(yo_row + (hasN ? L.sx : 0), lo));
+  const int64_t inplane = (int64_t)j * L.sx + 2 * t; // offset inside one plane
+  d2      oD = (HALO && k == 0 && halo.glo) ? ld2_sys(halo.glo + inplane) : ld2(at_bytes(yo_row - (hasD ? L.sp : 0), lo));
+  d2      oU = (HALO && k == L.nz - 1 && halo.ghi) ? ld2_sys(halo.ghi + inplane) : ld2(at_bytes(yo_row + (hasU ? L.sp : 0), lo));
+#ifndef PMG_GRID_NO_NT
+  // b is read once and y_own written once per colour pass: non-temporal accesses keep them from displacing the other
+  // colour's lines, which five neighbouring rows re-read (measured: 612 -> 597 us per 512^3 sweep)
+  d2     bb = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(at_bytes(b_own + rowoff, lo)));
+#else
+  d2     bb = ld2(at_bytes(b_own + rowoff, lo));
+#endif
+  pmg::RngConsts K;
+  if (NOISY) {
+    __builtin_amdgcn_sched_barrier(0); // all eight requests go out before the generator starts
+    K = pmg::load_sincos_consts();     // scalar loads of the polynomial coefficients: issued here (the row pointers'
+    __builtin_amdgcn_sched_barrier(0); // registers are free again), waited for behind the Philox rounds
+  }
+
+  // the noise first, while the eight loads above are in flight: nothing below may touch a loaded value before z0, z1 exist
+  // (left alone the scheduler starts with the selects on Vc / ed and parks the wavefront on its first load before the
+  // ~150 instructions of the generator, which need no memory at all)
+  double z0 = 0.0, z1 = 0.0;
+  if (NOISY) {
+    pmg::normal_pair_fill((uint32_t)t, (uint32_t)(j + (int64_t)L.ny * kg), (uint32_t)op.sweep, ((uint32_t)(op.sweep >> 32) & 0x7fffffffu) | ((uint32_t)c << 31), op.key0, op.key1, tab_entry, tab, (int)threadIdx.x, K, z0, z1);
+    asm volatile("" : "+v"(Vc.x), "+v"(Vc.y), "+v"(ed), "+v"(oS.x), "+v"(oS.y), "+v"(oN.x), "+v"(oN.y), "+v"(oD.x), "+v"(oD.y), "+v"(oU.x), "+v"(oU.y), "+v"(bb.x), "+v"(bb.y) : "v"(z0), "v"(z1));
+  }
+  const double L0 = p ? Vc.x : ed, R0 = p ? Vc.y : Vc.x, L1 = R0, R1 = p ? ed : Vc.y;
   const double idg0 = two0 ? idB : idA, idg1 = two1 ? idB : idA;
   const double hS = hasS ? h2 : 0.0, hN = hasN ? h2 : 0.0, hD = hasD ? h2 : 0.0, hU = hasU ? h2 : 0.0;
 
   double w0 = bb.x, w1 = bb.y;
   if (NOISY) {
-    double z0, z1;
-    pmg::normal_pair((uint32_t)t, (uint32_t)(j + (int64_t)L.ny * kg), (uint32_t)op.sweep, ((uint32_t)(op.sweep >> 32) & 0x7fffffffu) | ((uint32_t)c << 31), op.key0, op.key1, tab, z0, z1);
-    const double sqA = table_at<PACKED>(op.sqrtdiag, nyz + 1), sqB = table_at<PACKED>(op.sqrtdiag, nyz + 2);
     const double sq0 = two0 ? sqB : sqA, sq1 = two1 ? sqB : sqA;
     w0 = z0 * sq0 + bb.x;
     w1 = z1 * sq1 + bb.y;
@@ -188,13 +217,23 @@ __device__ __forceinline__ void grid_color_sweep_body(const pmgk_grid_layout &L,
     r0 = idg0 * s0;
     r1 = idg1 * s1;
   } else {
-    const d2 yo2 = ld2(at_bytes(y_own + rowoff, lo));
+    const d2 yo2 = ld2(at_bytes(out_row, lo));
     r0           = op.one_minus_omega * yo2.x + idg0 * s0;
     r1           = op.one_minus_omega * yo2.y + idg1 * s1;
   }
   // the slot of a non-existent second point (odd nx) is a pad slot of this line: keep it zero
   const d2 out = {r0, v1 ? r1 : 0.0};
-  *reinterpret_cast<d2 *>(at_bytes(y_own + rowoff, lo)) = out;
+  if (NOISY) {
+    // the whole computation stays in front of this exit (the optimiser would otherwise sink the streaming loads into the
+    // `live` branch, behind the noise)
+    asm volatile("" ::"v"(out.x), "v"(out.y), "s"(out_row));
+    if (!live) return;
+  }
+#ifndef PMG_GRID_NO_NT
+  __builtin_nontemporal_store(out, reinterpret_cast<d2 *>(at_bytes(out_row, lo)));
+#else
+  *reinterpret_cast<d2 *>(at_bytes(out_row, lo)) = out;
+#endif
   if (HALO) {
     if (k == 0 && halo.plo) st2_sys(halo.plo + inplane, out);
     if (k == L.nz - 1 && halo.phi) st2_sys(halo.phi + inplane, out);
@@ -227,13 +266,21 @@ __device__ __forceinline__ void grid_thread_position(int nbx, int bandw, int ty,
 // nearly empty wavefront per line.  Same arithmetic per point and noise addressed by grid position, so the mapping does
 // not change the results.
 template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED, bool TAIL>
-__global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, int kcount, int tmain, int tailw, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, int kcount, int tmain, int tailw, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
 {
   // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
   // wave-uniform; readfirstlane tells the compiler, which then keeps the boundary logic on the scalar unit
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
   __shared__ pmg::LogTabEntry s_logtab[NOISY ? 4 * PMG_LOGTAB_SIZE : 1];
-  const pmg::LogTabEntry     *tab = s_logtab + (NOISY ? ty * PMG_LOGTAB_SIZE : 0);
+  pmg::LogTabEntry           *tab = s_logtab + (NOISY ? ty * PMG_LOGTAB_SIZE : 0);
+  // this lane's entry of the log table: requested FIRST, used last (normal_pair_fill) -- the fetch overlaps the
+  // wavefront's streaming loads instead of standing in front of them (round 4; round 3 filled the LDS copy here and
+  // waited: two dependent L2 round trips before a wavefront had a single load in flight)
+  pmg::LogTabEntry            tab_entry = {0.0, 0.0};
+  if (NOISY) {
+    const d2 e = ld2(reinterpret_cast<const double *>(pmg::g_logtab + threadIdx.x));
+    tab_entry  = {e.x, e.y};
+  }
   int                         t, j;
   if (TAIL && (int)blockIdx.z >= kcount) {
     const int tb  = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * ((int)blockIdx.z - kcount));
@@ -248,7 +295,6 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
     const int  per     = (slots + 255) / 256; // tail blocks per plane
     const int  kz = tb / per, part = tb - kz * per;
     if (kz >= kcount) return;
-    if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x);
     const int f = (part * 4 + ty) * 64 + (int)threadIdx.x, kt = kbegin + kz * kstride;
     if (compact) {
       j = 2 * f + ((c + kt + L.kz0) & 1);
@@ -257,10 +303,9 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
       j = f / tailw;
       t = tmain + f - j * tailw;
     }
-    grid_color_sweep_body<NOISY, OMEGA1, false, true>(L, op, c, t, j, kt, tab, halo, b_own, y_other, y_own);
+    grid_color_sweep_body<NOISY, OMEGA1, false, true>(L, op, c, t, j, kt, tab, tab_entry, halo, b_own, y_other, y_own);
     return;
   }
-  if (NOISY) pmg::load_log_table_wave(s_logtab + ty * PMG_LOGTAB_SIZE, threadIdx.x); // (gathering from the global table instead: 0.60 vs 0.62)
   grid_thread_position<PACKED>(nbx, bandw, ty, t, j);
 
   int k = kbegin + (int)blockIdx.z * kstride;
@@ -270,7 +315,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
     const bool face_lo = k == 0, face_hi = k == L.nz - 1;
     if (face_lo && halo.wlo) wave_wait_flag(halo.wlo, halo.wval, halo.err);
     if (face_hi && halo.whi) wave_wait_flag(halo.whi, halo.wval, halo.err);
-    grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, t, j, k, tab, halo, b_own, y_other, y_own);
+    grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, t, j, k, tab, tab_entry, halo, b_own, y_other, y_own);
     if (face_lo || face_hi) { // every block of a face plane reports; the last one tells the neighbours
       // the peer stores are system-scope write-through stores (st2_sys): waiting for their completion is all a
       // wavefront has to do -- a system-scope release FENCE here would also write the whole L2 back, once per
@@ -295,7 +340,7 @@ __global__ __launch_bounds__(256) void grid_color_sweep_kernel(pmgk_grid_layout 
     }
     return;
   }
-  grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, t, j, k, tab, halo, b_own, y_other, y_own);
+  grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, t, j, k, tab, tab_entry, halo, b_own, y_other, y_own);
 }
 
 // natural (DMDA, i fastest) <-> colour-partitioned storage

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "pmg_kernels.h"
+#define PMG_RNG_TU st27
 #include "pmg_rng.hpp"
 
 namespace {

@@ -8,7 +8,8 @@
 // The transcendental part is hand-written for the fp64 VALU (the sweep is VALU-bound with the stock libm
 // calls): both uniforms stay 53-bit INTEGERS as long as possible --
 //   ln u1 : exponent/mantissa split on the integer, z in [0.6875,1.375) so that u -> 1 needs no cancelling
-//           k*ln2 term, 89-entry {1/c, ln c} table (c = i/128) in LDS, r = z/c - 1 by one fma, degree-7 log1p;
+//           k*ln2 term, 64-entry {1/c, ln c} table (c = i/92: one entry per lane of a wavefront, so ONE 16-byte load
+//           per lane fills a wavefront's copy) in LDS, r = z/c - 1 by one fma, degree-7 log1p;
 //   sqrt  : v_rsq_f64 + one Goldschmidt step + two residual corrections;
 //   sin/cos(2 pi u2): quadrant from the top bits of the integer, remainder |r| <= 1/8 turn converted exactly,
 //           Taylor series in turns (no multiplication by pi, no range-reduction error).
@@ -60,6 +61,79 @@ __device__ __forceinline__ double fma_vsv(double a, double c, double b) // a * c
   return r;
 }
 
+// The fp64 constants of the transform, fetched with SCALAR loads (s_load_dwordx8/x16 from constant memory) instead of being
+// materialised by two s_mov_b32 each: the sweep kernels issue as many scalar as vector instructions, the CU's one scalar
+// unit serves four SIMDs, and 24 constants were 48 of ~230 scalar instructions per wavefront (tools/valubench.hip: an
+// s_mov_b32 costs a SIMD's issue port what a v_fma_f64 does).  Not `const`: the optimiser would fold the values back into
+// literals.  For the same reason the array has EXTERNAL linkage (a `static` one that nothing in the translation unit
+// writes is folded just the same), so every kernel file names its copy: #define PMG_RNG_TU <tag> before this header.
+#ifndef PMG_RNG_TU
+#error "define PMG_RNG_TU (a tag unique to the including .hip file) before including pmg_rng.hpp"
+#endif
+#define PMG_RNG_CAT2(a, b) a##b
+#define PMG_RNG_CAT(a, b) PMG_RNG_CAT2(a, b)
+#define g_rngc PMG_RNG_CAT(g_pmg_rngc_, PMG_RNG_TU)
+enum {
+  RC_SIN0 = 0, // .. RC_SIN0 + 8
+  RC_COS1 = 9, // .. RC_COS1 + 8  (COS_C1..C9)
+  RC_LOG0  = 18,
+  RC_THIRD = 18,
+  RC_MSIXTH,
+  RC_FIFTH,
+  RC_SEVENTH,
+  RC_LN2_HI,
+  RC_LN2_LO,
+  RC_COUNT
+};
+#define PMG_RNGC_VALUES PMG_SIN_C0, PMG_SIN_C1, PMG_SIN_C2, PMG_SIN_C3, PMG_SIN_C4, PMG_SIN_C5, PMG_SIN_C6, PMG_SIN_C7, PMG_SIN_C8, PMG_COS_C1, PMG_COS_C2, PMG_COS_C3, PMG_COS_C4, PMG_COS_C5, PMG_COS_C6, PMG_COS_C7, PMG_COS_C8, PMG_COS_C9, 1.0 / 3.0, -1.0 / 6.0, 0.2, 1.0 / 7.0, PMG_LN2_HI, PMG_LN2_LO
+__constant__ double g_rngc[RC_COUNT] = {PMG_RNGC_VALUES};
+
+// ONE base address in a scalar register pair (opaque to the optimiser, which would otherwise address every element
+// pc-relative by itself) and constant-address-space loads at immediate offsets from it, which the backend merges into
+// s_load_dwordx4/x8/x16
+typedef const double __attribute__((address_space(4))) *rng_consts_t;
+__device__ __forceinline__ rng_consts_t rng_consts()
+{
+  rng_consts_t p = (rng_consts_t)(unsigned long long)&g_rngc[0];
+  asm("" : "+s"(p));
+  return p;
+}
+
+// in scalar registers, in two groups so that a wavefront stays within the 96 SGPRs that eight wavefronts per SIMD allow:
+// a kernel calls load_sincos_consts() where it wants those loads ISSUED (in front of the Philox rounds: they are waited
+// for only at the first use); the six of the logarithm are fetched behind the sin/cos polynomials, whose registers they
+// take over, in the shadow of the table exchange through LDS
+struct RngConsts {
+  double c[RC_LOG0];
+};
+struct RngLogConsts {
+  double c[RC_COUNT - RC_LOG0];
+};
+__device__ __forceinline__ RngConsts load_sincos_consts()
+{
+#ifndef PMG_RNG_LITERALS
+  const rng_consts_t p = rng_consts();
+#else
+  constexpr double p[RC_COUNT] = {PMG_RNGC_VALUES};
+#endif
+  RngConsts K;
+#pragma unroll
+  for (int i = 0; i < RC_LOG0; ++i) K.c[i] = p[i];
+  return K;
+}
+__device__ __forceinline__ RngLogConsts load_log_consts()
+{
+#ifndef PMG_RNG_LITERALS
+  const rng_consts_t p = rng_consts();
+#else
+  constexpr double p[RC_COUNT] = {PMG_RNGC_VALUES};
+#endif
+  RngLogConsts K;
+#pragma unroll
+  for (int i = 0; i < RC_COUNT - RC_LOG0; ++i) K.c[i] = p[RC_LOG0 + i];
+  return K;
+}
+
 struct LogTabEntry {
   double invc, logc;
 };
@@ -76,8 +150,8 @@ __device__ __forceinline__ void load_log_table(LogTabEntry *lds_tab)
 // operations execute in order, the wave barrier only stops the compiler from reordering them.
 __device__ __forceinline__ void load_log_table_wave(LogTabEntry *wave_tab, int lane)
 {
+  static_assert(PMG_LOGTAB_SIZE == 64, "one table entry per lane");
   wave_tab[lane] = g_logtab[lane];
-  if (lane < PMG_LOGTAB_SIZE - 64) wave_tab[64 + lane] = g_logtab[64 + lane];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -94,26 +168,30 @@ __device__ __forceinline__ void u53_int(uint32_t lo, uint32_t hi, uint32_t &xlo,
 }
 
 // s = -2 ln(X * 2^-53), X = xhi:xlo in [1, 2^53]
-__device__ __forceinline__ double minus2_log_u(uint32_t xlo, uint32_t xhi, const LogTabEntry *tab)
+__device__ __forceinline__ double minus2_log_u(uint32_t xlo, uint32_t xhi, const LogTabEntry *tab, const RngLogConsts &K)
 {
+  const double *rc = K.c - RC_LOG0;
   const double d = fma_vsv((double)xhi, 4294967296.0, (double)xlo); // exact
   // d = 2^k' * z with z in [0.6875, 1.375): subtract the bit pattern of 0.6875 from the high word
   const uint32_t dh  = (uint32_t)__double2hiint(d);
   const uint32_t tmp = dh - 0x3fe60000u;
   const int      k   = (int)tmp >> 20; // exponent of d relative to z
   const double   z   = __hiloint2double((int)(dh - ((uint32_t)k << 20)), __double2loint(d));
-  const int      i   = (int)fma(z, 128.0, 0.5); // round(z*128) in [88,176]
+  const int      i   = (int)fma(z, PMG_LOGTAB_SCALE, 0.5); // round(z*92) in [63,126]
   const LogTabEntry e = tab[i - PMG_LOGTAB_FIRST];
-  const double   r  = fma(z, e.invc, -1.0); // z/c - 1, |r| <= 1/176
+  const double   r  = fma(z, e.invc, -1.0); // z/c - 1, |r| <= 1/126
   const double   w  = r * r;
-  // log1p(r) = r - w/2 + r w (1/3 - r/4 + w (1/5 - r/6 + w/7))
-  const double A  = fma(r, -0.25, 1.0 / 3.0);
-  const double B  = fma(r, -1.0 / 6.0, 0.2);
-  const double q  = fma(w, fma_vsv(w, 1.0 / 7.0, B), A);
+  // log1p(r) = r - w/2 + r w (1/3 - r/4 + r^2/5 - r^3/6 + r^4/7), Horner in r: one constant per step, each from a scalar
+  // register pair
+  double q = r * rc[RC_SEVENTH];
+  q        = q + rc[RC_MSIXTH];
+  q        = fma_vvs(q, r, rc[RC_FIFTH]);
+  q        = fma(q, r, -0.25);
+  q        = fma_vvs(q, r, rc[RC_THIRD]);
   const double lp = fma(r * w, q, fma(w, -0.5, r));
   const double kd = (double)(k - 53); // ln u = (k-53) ln2 + ln c + log1p(r)
-  const double hi = fma_vsv(kd, PMG_LN2_HI, e.logc);
-  const double ln = hi + fma_vsv(kd, PMG_LN2_LO, lp);
+  const double hi = fma_vsv(kd, rc[RC_LN2_HI], e.logc);
+  const double ln = hi + fma_vsv(kd, rc[RC_LN2_LO], lp);
   return -2.0 * ln;
 }
 
@@ -134,29 +212,30 @@ __device__ __forceinline__ double sqrt_pos(double s)
 }
 
 // sin and cos of 2 pi Y 2^-53 for the integer Y = yhi:ylo in [1, 2^53]
-__device__ __forceinline__ void sincos_turns(uint32_t ylo, uint32_t yhi, double &sn, double &cs)
+__device__ __forceinline__ void sincos_turns(uint32_t ylo, uint32_t yhi, const RngConsts &K, double &sn, double &cs)
 {
+  const double *rc = K.c;
   const uint32_t q  = (yhi + (1u << 18)) >> 19;        // nearest quarter turn, 0..4
   const int32_t  rh = (int32_t)(yhi - (q << 19));      // remainder Y - q 2^51 in [-2^50, 2^50], high word
   const double   r  = fma_vsv((double)rh, 4294967296.0, (double)ylo) * 0x1.0p-53; // turns, |r| <= 1/8, exact
   const double   w  = r * r;
-  double s = PMG_SIN_C8, c = PMG_COS_C9;
-  s = fma_vvs(s, w, PMG_SIN_C7);
-  c = fma_vvs(c, w, PMG_COS_C8);
-  s = fma_vvs(s, w, PMG_SIN_C6);
-  c = fma_vvs(c, w, PMG_COS_C7);
-  s = fma_vvs(s, w, PMG_SIN_C5);
-  c = fma_vvs(c, w, PMG_COS_C6);
-  s = fma_vvs(s, w, PMG_SIN_C4);
-  c = fma_vvs(c, w, PMG_COS_C5);
-  s = fma_vvs(s, w, PMG_SIN_C3);
-  c = fma_vvs(c, w, PMG_COS_C4);
-  s = fma_vvs(s, w, PMG_SIN_C2);
-  c = fma_vvs(c, w, PMG_COS_C3);
-  s = fma_vvs(s, w, PMG_SIN_C1);
-  c = fma_vvs(c, w, PMG_COS_C2);
-  s = fma_vvs(s, w, PMG_SIN_C0);
-  c = fma_vvs(c, w, PMG_COS_C1);
+  double s = rc[RC_SIN0 + 8], c = rc[RC_COS1 + 8];
+  s = fma_vvs(s, w, rc[RC_SIN0 + 7]);
+  c = fma_vvs(c, w, rc[RC_COS1 + 7]);
+  s = fma_vvs(s, w, rc[RC_SIN0 + 6]);
+  c = fma_vvs(c, w, rc[RC_COS1 + 6]);
+  s = fma_vvs(s, w, rc[RC_SIN0 + 5]);
+  c = fma_vvs(c, w, rc[RC_COS1 + 5]);
+  s = fma_vvs(s, w, rc[RC_SIN0 + 4]);
+  c = fma_vvs(c, w, rc[RC_COS1 + 4]);
+  s = fma_vvs(s, w, rc[RC_SIN0 + 3]);
+  c = fma_vvs(c, w, rc[RC_COS1 + 3]);
+  s = fma_vvs(s, w, rc[RC_SIN0 + 2]);
+  c = fma_vvs(c, w, rc[RC_COS1 + 2]);
+  s = fma_vvs(s, w, rc[RC_SIN0 + 1]);
+  c = fma_vvs(c, w, rc[RC_COS1 + 1]);
+  s = fma_vvs(s, w, rc[RC_SIN0 + 0]);
+  c = fma_vvs(c, w, rc[RC_COS1 + 0]);
   s = s * r;
   c = fma(c, w, 1.0);
   // rotate by q quarter turns: q odd swaps, sin negated for q = 2,3, cos negated for q = 1,2
@@ -168,15 +247,38 @@ __device__ __forceinline__ void sincos_turns(uint32_t ylo, uint32_t yhi, double 
 }
 
 // One Box-Muller pair from one Philox block.  z0 = r cos(2 pi u2), z1 = r sin(2 pi u2).
+// DEFERRED table fill: the caller requested its lane's table entry (`entry` = g_logtab[lane], a global load that may still be
+// in flight) before it issued its own streaming loads; the entry goes into the wavefront's LDS copy only here, behind the
+// Philox rounds, so that no wavefront sits on a table fetch before its streaming loads are out.  EVERY lane of the
+// wavefront must get here (lane i provides entry i).
+__device__ __forceinline__ void normal_pair_fill(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, LogTabEntry entry, LogTabEntry *wave_tab, int lane, const RngConsts &K, double &z0, double &z1)
+{
+  const Philox4 p = philox4x32_10(c0, c1, c2, c3, k0, k1);
+  uint32_t      xlo, xhi, ylo, yhi;
+  u53_int(p.r0, p.r1, xlo, xhi);
+  u53_int(p.r2, p.r3, ylo, yhi);
+  double s, c;
+  sincos_turns(ylo, yhi, K, s, c);
+  const RngLogConsts KL = load_log_consts();
+  wave_tab[lane]        = entry;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const double radius = sqrt_pos(minus2_log_u(xlo, xhi, wave_tab, KL));
+  z0 = radius * c;
+  z1 = radius * s;
+}
+
 __device__ __forceinline__ void normal_pair(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, const LogTabEntry *tab, double &z0, double &z1)
 {
   const Philox4 p = philox4x32_10(c0, c1, c2, c3, k0, k1);
   uint32_t      xlo, xhi, ylo, yhi;
   u53_int(p.r0, p.r1, xlo, xhi);
   u53_int(p.r2, p.r3, ylo, yhi);
-  const double radius = sqrt_pos(minus2_log_u(xlo, xhi, tab));
-  double       s, c;
-  sincos_turns(ylo, yhi, s, c);
+  const RngConsts K      = load_sincos_consts();
+  const double    radius = sqrt_pos(minus2_log_u(xlo, xhi, tab, load_log_consts()));
+  double          s, c;
+  sincos_turns(ylo, yhi, K, s, c);
   z0 = radius * c;
   z1 = radius * s;
 }
