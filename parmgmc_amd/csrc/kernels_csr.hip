@@ -13,6 +13,7 @@
 // row itself.  Vectors handled here are in the permuted numbering.
 #include <hip/hip_runtime.h>
 #include "pmg_kernels.h"
+#define PMG_RNG_LITERALS // the transform's constants as literals here: scalar loads in the middle of these kernels' sums cost more than they save (st27 phase +9 % by GRBM_GUI_ACTIVE)
 #define PMG_RNG_TU csr
 #include "pmg_rng.hpp"
 

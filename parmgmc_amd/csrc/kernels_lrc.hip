@@ -7,6 +7,9 @@
 // column-major with leading dimension ld, rows in the sampler's storage layout -- 8 N k bytes, HBM bound.
 #include <hip/hip_runtime.h>
 #include "pmg_kernels.h"
+#define PMG_RNG_LITERALS // the transform's constants as literals here: scalar loads in the middle of these kernels' sums cost more than they save (st27 phase +9 % by GRBM_GUI_ACTIVE)
+#define PMG_RNG_TU lrc
+#include "pmg_rng.hpp"
 
 namespace {
 
@@ -93,21 +96,34 @@ __global__ __launch_bounds__(256) void lrc_btx_rows_partial_kernel(int64_t ns, i
 {
   __shared__ double red[64][4];
   const int64_t q0 = (int64_t)blockIdx.x * 4096 + threadIdx.x;
-  double        yv[16];
+  // three dependent fetches (positions -> y at the positions; the factors) from cold memory are what this kernel takes its
+  // time for: the first column's factors are requested together with the positions, in front of the gathers that wait for
+  // them, and every further column in front of the sum of the one before (round 4)
+  int64_t rr[16];
+  double  yv[16], m[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int64_t q = q0 + 256 * i;
-    yv[i]           = q < ns ? y[rows[q]] : 0.0;
+    rr[i]           = q < ns ? rows[q] : -1;
   }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t q = q0 + 256 * i;
+    m[i]            = q < ns ? Mc[q] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) yv[i] = rr[i] >= 0 ? y[rr[i]] : 0.0;
   for (int c0 = 0; c0 < k; c0 += 64) { // k <= 64 in practice: one round
     const int kc = min(64, k - c0);
     for (int c = 0; c < kc; ++c) {
-      const double *col = Mc + ns * (int64_t)(c0 + c);
-      double        m[16];
+      double mn[16];
+      if (c0 + c + 1 < k) {
+        const double *col = Mc + ns * (int64_t)(c0 + c + 1);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int64_t q = q0 + 256 * i;
-        m[i]            = q < ns ? col[q] : 0.0;
+        for (int i = 0; i < 16; ++i) {
+          const int64_t q = q0 + 256 * i;
+          mn[i]           = q < ns ? col[q] : 0.0;
+        }
       }
       double s = 0.0;
 #pragma unroll
@@ -116,6 +132,10 @@ __global__ __launch_bounds__(256) void lrc_btx_rows_partial_kernel(int64_t ns, i
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
       if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = s;
+      if (c0 + c + 1 < k) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = mn[i];
+      }
     }
     __syncthreads();
     if ((int)threadIdx.x < kc) partial[(int64_t)blockIdx.x * k + c0 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
@@ -148,9 +168,141 @@ __global__ void lrc_mul_kernel(int k, const double *__restrict__ a, const double
   if (c < k) out[c] = a[c] * b[c];
 }
 
+// ---- round 4: the per-sweep chain of the row-compact form in four launches instead of seven -------------------------------
+// (profiles/r03_cycles_summary.json: at 257^3, k = 3 the low-rank V-cycle sample was 101 launches, 69 of them these small
+// kernels at their launch floor -- +57 % time for three columns on 2 % of the rows).  What was also built and REMOVED: the
+// partial sums and their reduction in one launch, the last block to finish adding them up behind a device-wide ticket
+// (__threadfence + atomic, as the halo hand-shake of kernels_grid.hip): bit-identical, but 12-22 us per launch against
+// 9.5 + 2.5 for the two kernels -- on this chip the fence that publishes a block's sums to the other XCDs' L2s costs more than
+// the launch boundary it saves (gpurun_out/r4_lrc_trace.log; the V-cycle sample 0.900 ms fused against 0.879).
+
+// Block-wide sum of the k column sums of one block of 4096 compact rows, exactly as lrc_btx_rows_partial_kernel forms them:
+// a thread owns the rows q0 + 256 i, i < 16, in ascending order; wavefront shuffle tree; (red0 + red1) + (red2 + red3).
+// Thread c < kc holds the block's sum of column c0 + c on return (others: unspecified).  red: [64][4] doubles of LDS.
+__device__ __forceinline__ double lrc_block_colsum(int64_t ns, int kc, int64_t col0, const double *__restrict__ Mc, const double (&yv)[16], int64_t q0, double (*red)[4])
+{
+  for (int c = 0; c < kc; ++c) {
+    const double *col = Mc + ns * (col0 + c);
+    double        m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t q = q0 + 256 * i;
+      m[i]            = q < ns ? col[q] : 0.0;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (q0 + 256 * i < ns) s = fma(m[i], yv[i], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  double r = 0.0;
+  if ((int)threadIdx.x < kc) r = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  __syncthreads();
+  return r;
+}
+
+// v[rows[q]] += sign * sum_c Mc[q + ns c] coef[c] (lrc_axpy_rows_kernel) and, in the same pass over the support rows,
+// w[rows[q]] = save[q]: the right-hand side entries under the noise term go back behind the sweep (lrc_scatter_rows_kernel)
+__global__ __launch_bounds__(256) void lrc_axpy_restore_rows_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, const double *__restrict__ coef, double sign, double *__restrict__ v, const double *__restrict__ save, double *__restrict__ w)
+{
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= ns) return;
+  double s = 0.0;
+  for (int c = 0; c < k; ++c) s = fma(Mc[q + ns * c], coef[c], s);
+  const int64_t r = rows[q];
+  v[r]            = v[r] + sign * s;
+  w[r]            = save[q];
+}
+
+// fill_normal_rows_kernel + lrc_mul_kernel + lrc_axpy_rows_kernel(save) in one launch: EVERY block draws the k normals of
+// the row stream (seed, sweep) itself -- counter-based: the same numbers in every block -- scales them by sqrt(S) and adds
+// B eta to the support rows of b, keeping the old entries.  Same draws (pair c >> 1, branch c & 1), same roundings.
+__global__ __launch_bounds__(256) void lrc_rhs_rows_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, const double *__restrict__ sqrtS, uint32_t key0, uint32_t key1, uint64_t sweep, double *__restrict__ b, double *__restrict__ save)
+{
+  __shared__ pmg::LogTabEntry s_logtab[PMG_LOGTAB_SIZE];
+  __shared__ double           s_eta[64];
+  pmg::load_log_table(s_logtab);
+  __syncthreads();
+  if (2 * (int)threadIdx.x < k) {
+    const uint32_t p = threadIdx.x;
+    double         z0, z1;
+    pmg::normal_pair(p, 0u, (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
+    s_eta[2 * p] = z0 * sqrtS[2 * p];
+    if (2 * (int)p + 1 < k) s_eta[2 * p + 1] = z1 * sqrtS[2 * p + 1];
+  }
+  __syncthreads();
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= ns) return;
+  double s = 0.0;
+  for (int c = 0; c < k; ++c) s = fma(Mc[q + ns * c], s_eta[c], s);
+  const int64_t r = rows[q];
+  const double  o = b[r];
+  save[q]         = o;
+  b[r]            = o + 1.0 * s;
+}
+
+// Small supports (one block of 4096 rows): B^T y AND the update that consumes it in ONE launch of one workgroup --
+//   wk = scale o (M1^T y[rows1]);  v[rows2] += sign * M2 wk;  optionally w[rows2] = save[q]
+// (rows1 / M1 = the support of B on the level whose vector is read, rows2 / M2 = the block that is applied: Bb of the same
+// level for the post-correction, B of the next coarser level for the restricted residual term).  Same sums in the same
+// order as the separate kernels.
+__global__ __launch_bounds__(256) void lrc_btx_axpy_small_kernel(int64_t ns1, int k, const double *__restrict__ M1, const int64_t *__restrict__ rows1, const double *y, const double *__restrict__ scale, double *__restrict__ wk, int64_t ns2, const double *__restrict__ M2, const int64_t *__restrict__ rows2, double sign, double *v, const double *__restrict__ save, double *w)
+{
+  __shared__ double red[64][4];
+  __shared__ double s_wk[64];
+  const int64_t     q0 = threadIdx.x;
+  double            yv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t q = q0 + 256 * i;
+    yv[i]           = q < ns1 ? y[rows1[q]] : 0.0;
+  }
+  // k <= 64: one round (the host checks)
+  const double r = lrc_block_colsum(ns1, k, 0, M1, yv, q0, red);
+  if ((int)threadIdx.x < k) {
+    // lrc_reduce_kernel with one block: lane 0 holds the block's sum, the others add zeros
+    const double t = scale ? scale[threadIdx.x] * r : r;
+    s_wk[threadIdx.x] = t;
+    wk[threadIdx.x]   = t;
+  }
+  __syncthreads();
+  for (int64_t q = threadIdx.x; q < ns2; q += 256) {
+    double s = 0.0;
+    for (int c = 0; c < k; ++c) s = fma(M2[q + ns2 * c], s_wk[c], s);
+    const int64_t rr = rows2[q];
+    v[rr]            = v[rr] + sign * s;
+    if (save) w[rr] = save[q];
+  }
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
+
+extern "C" int pmgk_lrc_axpy_restore_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *coef, double sign, double *v, const double *save, double *w, void *stream)
+{
+  if (ns <= 0) return 0;
+  hipLaunchKernelGGL(lrc_axpy_restore_rows_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, coef, sign, v, save, w);
+  return launch_status();
+}
+
+extern "C" int pmgk_lrc_rhs_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *sqrtS, uint64_t seed, uint64_t sweep, double *b, double *save, void *stream)
+{
+  if (ns <= 0 || k <= 0 || k > 64) return k > 64;
+  hipLaunchKernelGGL(lrc_rhs_rows_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, sqrtS, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, save);
+  return launch_status();
+}
+
+/* one workgroup: ns1 <= 4096 (one block of lrc_btx_rows_partial_kernel), k <= 64; ns2 is looped over */
+extern "C" int pmgk_lrc_btx_axpy_small(int64_t ns1, int k, const double *M1, const int64_t *rows1, const double *y, const double *scale, double *wk, int64_t ns2, const double *M2, const int64_t *rows2, double sign, double *v, const double *save, double *w, void *stream)
+{
+  if (ns1 <= 0 || ns1 > 4096 || k <= 0 || k > 64) return 1;
+  hipLaunchKernelGGL(lrc_btx_axpy_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ns1, k, M1, rows1, y, scale, wk, ns2, M2, rows2, sign, v, save, w);
+  return launch_status();
+}
 
 extern "C" int pmgk_lrc_nblocks(int64_t n) { return (int)((n + 4095) / 4096); }
 

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "pmg_kernels.h"
+#define PMG_RNG_LITERALS // the transform's constants as literals here: scalar loads in the middle of these kernels' sums cost more than they save (st27 phase +9 % by GRBM_GUI_ACTIVE)
 #define PMG_RNG_TU st27
 #include "pmg_rng.hpp"
 

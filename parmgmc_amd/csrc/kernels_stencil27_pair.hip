@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "pmg_kernels.h"
+#define PMG_RNG_LITERALS // the transform's constants as literals here: scalar loads in the middle of these kernels' sums cost more than they save (st27 phase +9 % by GRBM_GUI_ACTIVE)
 #define PMG_RNG_TU st27pair
 #include "pmg_rng.hpp"
 
@@ -94,6 +95,7 @@ struct pair_ctx {
   uint32_t key0, key1;
   uint64_t sweep;
   double   om1;
+  const double *gcoef;
 };
 
 // New values of the two points of a pair.  FIRST1: the point x1 is swept before x0 (backward order).
@@ -128,7 +130,13 @@ __device__ __forceinline__ d2 sweep_pair(const pair_ctx &C, RowFn &&get_row, Zer
     w0 = z0 * s_sqrtd[cls0] + w0;
     w1 = z1 * s_sqrtd[cls1] + w1;
   }
+#ifdef PMG_ST27_PROBE_INTERIOR
+  // TIMING PROBE ONLY (wrong at the boundaries): every point takes the interior class, coefficients from scalar loads
+  typedef const double __attribute__((address_space(4))) *cptr;
+  const cptr cfF = (cptr)(unsigned long long)C.gcoef + 27 * 13, cfS = cfF;
+#else
   const double *cfF = s_coef + 27 * clsF, *cfS = s_coef + 27 * clsS;
+#endif
   double        accF = F ? w1 : w0, accS = S ? w1 : w0;
   double        oldF = 0.0, oldS = 0.0;
 #pragma unroll
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
   C.key1 = key1;
   C.sweep = sweep;
   C.om1   = one_minus_omega;
+  C.gcoef = S.coef;
   const int  xc0 = C.x0;
   const bool final_lane = lane >= HL && lane < HL + VALID; // lanes whose results are complete at the end of each stage
   const int  jt = 2 * PT * by;

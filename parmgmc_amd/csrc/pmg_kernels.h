@@ -145,6 +145,11 @@ int pmgk_lrc_gather_rows(int64_t ns, int k, const double *M, int64_t ld, const i
 int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *y, double *partial, const double *scale, double *out, void *stream);
 int pmgk_lrc_axpy_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *coef, double sign, double *v, double *save, void *stream);
 int pmgk_lrc_scatter_rows(int64_t ns, const int64_t *rows, const double *save, double *v, void *stream);
+/* fused forms (round 4): update + restore of the right-hand side; noise draw + scale + B eta;
+   B^T y and the update that consumes it in one workgroup (small supports) */
+int pmgk_lrc_axpy_restore_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *coef, double sign, double *v, const double *save, double *w, void *stream);
+int pmgk_lrc_rhs_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *sqrtS, uint64_t seed, uint64_t sweep, double *b, double *save, void *stream);
+int pmgk_lrc_btx_axpy_small(int64_t ns1, int k, const double *M1, const int64_t *rows1, const double *y, const double *scale, double *wk, int64_t ns2, const double *M2, const int64_t *rows2, double sign, double *v, const double *save, double *w, void *stream);
 int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);
 /* out[c] = sum over r = 0..nrows-1 (in that order) of in[r*count + c] */
 int pmgk_fill_zero(double *p, int64_t n, void *stream); /* p 16-byte aligned */

@@ -28,6 +28,16 @@ struct pmg_lrc_s {
   double  *Bc, *Bbc[2];      /* device, ns x k column-major */
   double  *saved;            /* device, ns: the right-hand side entries under the noise term */
   double  *b_mod;            /* the vector whose support rows currently carry the noise term */
+  int      restore_pending;  /* pmg_lrc_rhs_done has been called: the saved entries go back with the next pass over the support rows
+                                (the post-correction's update kernel), or by themselves if something else comes first */
+  /* Round 4 built the per-sweep chain in fewer launches -- the noise term in ONE kernel (draw + scale + B eta) instead of
+     three, the restore of the right-hand side inside the post-correction's update, one workgroup for B^T y and its update on
+     supports of at most 4096 rows -- bit-identical (tests/test_gpu_lrc_fused.py) and 101 -> 65 launches per 257^3 sample,
+     but NOT faster: 0.845 ms per sample against 0.826 for the chain of small kernels on the same box (either fusion alone:
+     0.853 / 0.870; tools/lrcbench.py, three interleaved runs, gpurun_out/r4_lrc3.log).  The chain of small kernels stays the
+     default; PMG_LRC_FUSED=1 (read when the object is built) selects the fused forms. */
+  int      unfused_rhs, unfused_restore;
+  int      unfused;
   int      empty;            /* this rank's rows do not meet the support of B at all (row-distributed operator) */
   pmg_lrc_reduce_fn reduce;  /* row-distributed operator: sum of the k-vectors over the ranks */
   void             *rctx;
@@ -162,6 +172,12 @@ pmg_status pmg_lrc_build_dev(pmg_lrc *out, int32_t k, int64_t ld, const double *
   l->ld     = ld;
   l->reduce = reduce;
   l->rctx   = rctx;
+  {
+    const char *e = getenv("PMG_LRC_FUSED"); /* 1: both fusions; 2: the noise term only; 3: the restore only */
+    l->unfused         = !(e && e[0] == '1');
+    l->unfused_rhs     = !(e && (e[0] == '1' || e[0] == '2'));
+    l->unfused_restore = !(e && (e[0] == '1' || e[0] == '3'));
+  }
   double sq[64];
   for (int c = 0; c < k; ++c) sq[c] = sqrt(fabs(S_host[c])); /* VecSqrtAbs(sqrtS), src/pc_mcgibbs.c:240-242 */
   pmg_status st = pmg_dev_alloc((void **)&l->B, sizeof(double) * (size_t)ld * k);
@@ -222,22 +238,46 @@ pmg_status pmg_lrc_build(pmg_lrc *out, int32_t k, int64_t ld, int32_t n, const d
   return st;
 }
 
+/* the saved right-hand side entries go back by themselves (nothing that passes over the support rows came in between) */
+static pmg_status lrc_flush_restore(pmg_lrc l, void *stream)
+{
+  if (l->restore_pending) {
+    PMG_KERNEL(pmgk_lrc_scatter_rows(l->ns, l->rows, l->saved, l->b_mod, stream));
+    l->restore_pending = 0;
+    l->b_mod           = NULL;
+  }
+  return PMG_SUCCESS;
+}
+
+/* one workgroup does B^T y and the update that consumes it (kernels_lrc.hip) when the support is one block of rows, the
+   update's row set is small and nothing has to be summed over ranks in between */
+static int lrc_small(pmg_lrc l, int64_t ns2) { return l->ns > 0 && l->ns <= 4096 && ns2 <= 16384 && !l->reduce && !l->unfused; }
+
 /* b_eff = b + B (sqrt(S) o eta), eta = row-stream normals of (seed + tag, counter); returns the device vector to
    sweep with.  Row-compact form: the noise term is added to the support rows of b IN PLACE (old values saved) and
-   b itself is returned -- pmg_lrc_rhs_done puts the saved values back after the sweep, bit for bit. */
+   b itself is returned -- pmg_lrc_rhs_done puts the saved values back after the sweep, bit for bit.  PMG_LRC_FUSED=1: ONE launch in the
+   row-compact form (every block draws the k normals itself). */
 pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t counter, const double **beff, void *stream)
 {
   if (l->empty) {
     *beff = b_lay;
     return PMG_SUCCESS;
   }
-  PMG_KERNEL(pmgk_fill_normal_rows(l->k, seed + 0x632BE59BD9B4E019ull, counter, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w) */
-  PMG_KERNEL(pmgk_lrc_mul(l->k, l->eta, l->sqrtS, l->eta, stream));                               /* VecPointwiseMult(w, w, sqrtS)   */
+  const uint64_t nseed = seed + 0x632BE59BD9B4E019ull;
   if (l->ns) {
+    PMG_CALL(lrc_flush_restore(l, stream));
     PMG_CHECK(!l->b_mod, PMG_ERR_ARG_WRONGSTATE, "pmg_lrc_rhs_done missing");
     l->b_mod = (double *)b_lay;
+    *beff    = b_lay;
+    if (!l->unfused_rhs) {
+      PMG_KERNEL(pmgk_lrc_rhs_rows(l->ns, l->k, l->Bc, l->rows, l->sqrtS, nseed, counter, l->b_mod, l->saved, stream)); /* VecSetRandomStandardNormal, VecPointwiseMult, MatMultAdd: src/pc_mcgibbs.c:130-140 */
+      return PMG_SUCCESS;
+    }
+  }
+  PMG_KERNEL(pmgk_fill_normal_rows(l->k, nseed, counter, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w) */
+  PMG_KERNEL(pmgk_lrc_mul(l->k, l->eta, l->sqrtS, l->eta, stream));        /* VecPointwiseMult(w, w, sqrtS)   */
+  if (l->ns) {
     PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->eta, 1.0, l->b_mod, l->saved, stream)); /* MatMultAdd(B, w, rhs, rhs) */
-    *beff = b_lay;
     return PMG_SUCCESS;
   }
   PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->B, l->ld, l->eta, 1.0, b_lay, l->beff, stream));  /* MatMultAdd(B, w, rhs, rhs)      */
@@ -245,13 +285,21 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
   return PMG_SUCCESS;
 }
 
-/* after the sweep that used the vector of pmg_lrc_rhs */
+/* after the sweep that used the vector of pmg_lrc_rhs: the saved entries are put back by the next pass over the support
+   rows -- pmg_lrc_post's update, which every sampler calls next -- or by a kernel of their own */
 pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream)
 {
   if (l->ns && l->b_mod) {
-    PMG_KERNEL(pmgk_lrc_scatter_rows(l->ns, l->rows, l->saved, l->b_mod, stream));
-    l->b_mod = NULL;
+    l->restore_pending = 1;
+    if (l->unfused_restore) PMG_CALL(lrc_flush_restore(l, stream));
   }
+  return PMG_SUCCESS;
+}
+
+/* wk = scale o (B^T x) over the support rows: partial sums per block of rows, then their sum in a fixed order */
+static pmg_status lrc_btx_compact(pmg_lrc l, const double *x_lay, const double *scale, void *stream)
+{
+  PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, x_lay, l->partial, scale, l->wk, stream));
   return PMG_SUCCESS;
 }
 
@@ -264,7 +312,12 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
     return l->reduce(l->rctx, l->wk, l->k, stream);
   }
   if (l->ns) {
-    PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, x_lay, l->partial, l->S, l->wk, stream));
+    PMG_CALL(lrc_flush_restore(l, stream));
+    if (lrc_small(l, l->ns)) {
+      PMG_KERNEL(pmgk_lrc_btx_axpy_small(l->ns, l->k, l->Bc, l->rows, x_lay, l->S, l->wk, l->ns, l->Bc, l->rows, -1.0, r_lay, NULL, NULL, stream));
+      return PMG_SUCCESS;
+    }
+    PMG_CALL(lrc_btx_compact(l, x_lay, l->S, stream));
     if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream)); /* S scales every partial sum alike */
     PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->wk, -1.0, r_lay, NULL, stream));
     return PMG_SUCCESS;
@@ -281,6 +334,7 @@ pmg_status pmg_lrc_get_compact(pmg_lrc l, int32_t *k, int64_t *ns, int64_t *rows
 {
   PMG_CHECK(l, PMG_ERR_ARG_NULL, "null handle");
   PMG_CHECK(l->ns > 0, PMG_ERR_SUP, "the low-rank factors of this level are kept dense");
+  PMG_CALL(lrc_flush_restore(l, NULL));
   if (k) *k = l->k;
   if (ns) *ns = l->ns;
   const size_t cb = sizeof(double) * (size_t)l->ns * (size_t)l->k;
@@ -302,8 +356,14 @@ pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc lf, pmg_lrc lc, const double 
 {
   PMG_CHECK(lf && lc && lf->k == lc->k, PMG_ERR_ARG_WRONG, "low-rank updates of two consecutive levels expected");
   /* S B_f^T x: per rank over its rows, summed over the ranks of a distributed level (a rank without rows contributes zeros) */
+  if (lf->ns) PMG_CALL(lrc_flush_restore(lf, stream));
+  if (lc->ns) PMG_CALL(lrc_flush_restore(lc, stream));
+  if (!lf->empty && !lc->empty && lc->ns && lrc_small(lf, lc->ns)) {
+    PMG_KERNEL(pmgk_lrc_btx_axpy_small(lf->ns, lf->k, lf->Bc, lf->rows, x_fine_lay, lf->S, lf->wk, lc->ns, lc->Bc, lc->rows, -1.0, b_coarse_lay, NULL, NULL, stream));
+    return PMG_SUCCESS;
+  }
   if (lf->empty) PMG_HIP(hipMemsetAsync(lf->wk, 0, sizeof(double) * (size_t)lf->k, (hipStream_t)stream));
-  else if (lf->ns) PMG_KERNEL(pmgk_lrc_btx_rows(lf->ns, lf->k, lf->Bc, lf->rows, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
+  else if (lf->ns) PMG_CALL(lrc_btx_compact(lf, x_fine_lay, lf->S, stream));
   else PMG_KERNEL(pmgk_lrc_btx(lf->ld, lf->k, lf->B, lf->ld, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
   if (lf->reduce) PMG_CALL(lf->reduce(lf->rctx, lf->wk, lf->k, stream));
   if (lc->empty) return PMG_SUCCESS; /* none of B_c's rows on this rank */
@@ -321,9 +381,21 @@ pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
     return l->reduce(l->rctx, l->wk, l->k, stream);
   }
   if (l->ns) {
-    PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, y_lay, l->partial, NULL, l->wk, stream));
-    if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream));
-    PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, NULL, stream));
+    /* the right-hand side entries under the noise term go back in the update's pass over the support rows */
+    const double *save = l->restore_pending && l->b_mod != y_lay ? l->saved : NULL;
+    double       *bmod = l->b_mod;
+    if (l->restore_pending && !save) PMG_CALL(lrc_flush_restore(l, stream));
+    if (lrc_small(l, l->ns)) PMG_KERNEL(pmgk_lrc_btx_axpy_small(l->ns, l->k, l->Bc, l->rows, y_lay, NULL, l->wk, l->ns, l->Bbc[d], l->rows, -1.0, y_lay, save, bmod, stream));
+    else {
+      PMG_CALL(lrc_btx_compact(l, y_lay, NULL, stream));
+      if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream));
+      if (save) PMG_KERNEL(pmgk_lrc_axpy_restore_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, save, bmod, stream));
+      else PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, NULL, stream));
+    }
+    if (save) {
+      l->restore_pending = 0;
+      l->b_mod           = NULL;
+    }
     return PMG_SUCCESS;
   }
   PMG_KERNEL(pmgk_lrc_btx(l->ld, l->k, l->B, l->ld, y_lay, l->partial, NULL, l->wk, stream));
