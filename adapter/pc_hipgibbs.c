@@ -267,8 +267,13 @@ static PetscErrorCode PCSetFromOptions_HipGibbs(PC pc, PetscOptionItems_ARG Pets
     PetscOptionsHeadBegin(PetscOptionsObject, "SOR Gibbs options");
     PetscCall(PetscOptionsBool("-pc_sorgibbs_forward", "SOR Gibbs forward sweep", NULL, (PetscBool)(hg->type == SOR_FORWARD_SWEEP), &flag, NULL));
     if (flag) hg->type = SOR_FORWARD_SWEEP;
-    /* -pc_sorgibbs_local_forward (the Hogwild variant, src/pc_sorgibbs.c:272-273) has no device counterpart: a
-       multicolour sweep on one device is already the exact Gauss-Seidel sweep */
+    /* -pc_sorgibbs_local_forward (the Hogwild variant: every rank sweeps its diagonal block with stale off-process values,
+       src/pc_sorgibbs.c:272-275) has no device counterpart -- on one device the multicolour sweep IS the exact Gauss-Seidel
+       sweep, on several ranks the row-block sweep exchanges ghost values per colour.  Asking for it is an error, not a
+       silently different sampler */
+    flag = PETSC_FALSE;
+    PetscCall(PetscOptionsBool("-pc_sorgibbs_local_forward", "SOR Gibbs local forward sweep (Hogwild): not supported on the device", NULL, PETSC_FALSE, &flag, NULL));
+    PetscCheck(!flag, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "-pc_sorgibbs_local_forward (Hogwild, src/pc_sorgibbs.c:272-275) is not supported by the device sampler: use -pc_sorgibbs_forward (exact sweep; on several ranks one ghost update per colour)");
   }
   /* not in the reference: the order of the device sweep.  Default: greedy multicolouring (few colours = few launches);
      lexicographic = the dependency levels of the natural order, i.e. PETSc MatSOR's result update for update */
@@ -370,6 +375,8 @@ PetscErrorCode PCCreate_HipMulticolorGibbs(PC pc)
 /* ---- exact coarse sampler: PCCreate_CholSampler, dense path (reference src/pc_chols.c:174-194,262-342) ------------- */
 typedef struct {
   pmg_chol    ch;
+  PetscInt    dense_threshold; /* -pc_cholsampler_dense_threshold (src/pc_chols.c:416): kept and shown; the device factorisation is dense at every size */
+  PetscBool   is_gamg_coarse;  /* -pc_cholsampler_coarse_gamg (src/pc_chols.c:415) */
   uint64_t    seed, counter, stream_id;
   HipStageBuf bbuf, ybuf;
   void *cbctx;
@@ -390,6 +397,11 @@ static PetscErrorCode PCSetUp_HipChol(PC pc)
 
   PetscFunctionBeginUser;
   PMGCall(pmg_chol_destroy(&hc->ch));
+  {
+    PetscMPIInt size;
+    PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)A), &size));
+    PetscCheck(size == 1, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "the device Cholesky sampler factors an operator that lives on ONE rank (as GAMG's coarse grid does, src/pc_chols.c:38-47); this one is spread over %d ranks", (int)size);
+  }
   PetscCall(PetscObjectTypeCompare((PetscObject)A, MATLRC, &islrc));
   if (islrc) { /* factor the explicit sum A + B S B^T, src/pc_chols.c:119-153 */
     PetscCall(HipGetLRC(pc->pmat, &A, &k, &B, &Bcopy, &Bmat, &S));
@@ -471,11 +483,34 @@ static PetscErrorCode PCDestroy_HipChol(PC pc)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* PCSetFromOptions_CholSampler (src/pc_chols.c:406-419), same keys.  What the device path does with them:
+     -pc_cholsampler_dense_threshold N : the reference factors sequential blocks of at most N rows densely (LAPACK) and larger
+        ones with a sparse direct solver; the device factorisation is dense (blocked MFMA Cholesky) at EVERY size, so the value
+        only decides nothing -- it is stored and shown by -ksp_view so that an option file of the reference is accepted;
+     -pc_cholsampler_coarse_gamg : the reference then factors on rank 0 only and scatters (GAMG leaves the coarse grid on one
+        rank, src/pc_chols.c:38-47,272-282).  Here the coarse operator must already live on ONE rank (PCSetUp checks it): a
+        coarse matrix spread over several ranks is an error with or without the flag, not a silent gather. */
+static PetscErrorCode PCSetFromOptions_HipChol(PC pc, PetscOptionItems_ARG PetscOptionsObject)
+{
+  PC_HipChol *hc   = (PC_HipChol *)pc->data;
+  PetscBool   flag = PETSC_FALSE;
+
+  PetscFunctionBeginUser;
+  PetscOptionsHeadBegin(PetscOptionsObject, "Cholesky options");
+  PetscCall(PetscOptionsBool("-pc_cholsampler_coarse_gamg", "Sampler is coarse GAMGMC sampler", NULL, flag, &flag, NULL));
+  if (flag) hc->is_gamg_coarse = PETSC_TRUE;
+  PetscCall(PetscOptionsInt("-pc_cholsampler_dense_threshold", "Sequential blocks of size <= this are factored and solved densely (the device path is dense at every size)", NULL, hc->dense_threshold, &hc->dense_threshold, NULL));
+  PetscOptionsHeadEnd();
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode PCView_HipChol(PC pc, PetscViewer viewer)
 {
-  (void)pc;
+  PC_HipChol *hc = (PC_HipChol *)pc->data;
+
   PetscFunctionBeginUser;
   PetscCall(PetscViewerASCIIPrintf(viewer, "Dense Cholesky sampler on the device (libparmgmc_hip %s, %s; MFMA f64 trailing updates)\n", pmg_version(), pmg_gpu_arch()));
+  PetscCall(PetscViewerASCIIPrintf(viewer, "dense_threshold %" PetscInt_FMT " (not used: dense at every size), coarse_gamg %s\n", hc->dense_threshold, hc->is_gamg_coarse ? "true" : "false"));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -501,12 +536,14 @@ PetscErrorCode PCCreate_HipCholSampler(PC pc)
   PetscFunctionBeginUser;
   PetscCall(PetscNew(&hc));
   hc->stream_id            = ParMGMCHipNextStreamId();
+  hc->dense_threshold      = 64; /* src/pc_chols.c:432 */
   pc->data                 = hc;
   pc->ops->setup           = PCSetUp_HipChol;
   pc->ops->apply           = PCApply_HipChol;
   pc->ops->applyrichardson = PCApplyRichardson_HipChol;
   pc->ops->destroy         = PCDestroy_HipChol;
   pc->ops->reset           = PCReset_HipChol;
+  pc->ops->setfromoptions  = PCSetFromOptions_HipChol;
   pc->ops->view            = PCView_HipChol;
   PetscCall(PCRegisterSetSampleCallback(pc, PCSetSampleCallback_HipChol));
   PetscFunctionReturn(PETSC_SUCCESS);

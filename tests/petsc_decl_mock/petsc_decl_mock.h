@@ -33,7 +33,15 @@ typedef int MPI_Op;
 #define MPI_BYTE 1
 #define MPI_INT 2
 #define MPI_MIN 3
+#define MPI_DOUBLE 4
+#define MPI_SUM 5
 #define MPI_SUCCESS 0
+#define MPI_COMM_WORLD 2
+/* the mock stands for a current PETSc (the reference's CI pins 3.25.1, .github/workflows/linux.yml:38) */
+#define PETSC_VERSION_LT(a, b, c) 0
+#define PETSC_VERSION_LE(a, b, c) 0
+#define PETSC_VERSION_GT(a, b, c) 1
+#define PETSC_VERSION_GE(a, b, c) 1
 typedef enum { DMDA_STENCIL_STAR, DMDA_STENCIL_BOX } DMDAStencilType;
 typedef enum { DM_BOUNDARY_NONE, DM_BOUNDARY_GHOSTED, DM_BOUNDARY_MIRROR, DM_BOUNDARY_PERIODIC } DMBoundaryType;
 #define PetscAbsReal(x) ((x) < 0 ? -(x) : (x))
@@ -43,7 +51,12 @@ typedef enum { PETSC_MEMTYPE_HOST = 0, PETSC_MEMTYPE_DEVICE = 1 } PetscMemType;
 #define PetscMemTypeDevice(m) (((m) & 0x1) == PETSC_MEMTYPE_DEVICE)
 #define PETSC_SUCCESS 0
 #define PETSC_ERR_SUP 56
+#define PETSC_ERR_ORDER 58
 #define PETSC_ERR_ARG_SIZ 60
+#define PETSC_ERR_MAT_LU_ZRPVT 71
+#define PETSC_ERR_PLIB 77
+#define PETSC_DECIDE (-1)
+#define PetscAbs(a) (((a) >= 0) ? (a) : (-(a)))
 #define PETSC_ERR_GPU 97
 #define PETSC_COMM_SELF 1
 #define PETSC_EXTERN extern
@@ -57,6 +70,16 @@ typedef struct _p_PetscRandom *PetscRandom;
 typedef struct _n_PetscOptions *PetscOptions;
 typedef struct _p_PetscOptionItems *PetscOptionItems;
 typedef struct _p_PC *PC;
+typedef struct _p_PetscDS     *PetscDS;
+typedef struct _n_ISColoring  *ISColoring;
+typedef unsigned short         ISColoringValue;
+typedef enum { IS_COLORING_GLOBAL, IS_COLORING_LOCAL } ISColoringType;
+typedef enum { PETSC_COPY_VALUES, PETSC_OWN_POINTER, PETSC_USE_POINTER } PetscCopyMode;
+typedef enum { MAT_DO_NOT_COPY_VALUES, MAT_COPY_VALUES, MAT_SHARE_NONZERO_PATTERN } MatDuplicateOption;
+typedef enum { NORM_1 = 0, NORM_2 = 1, NORM_FROBENIUS = 2, NORM_INFINITY = 3 } NormType;
+typedef enum { FILE_MODE_UNDEFINED = -1, FILE_MODE_READ = 0, FILE_MODE_WRITE } PetscFileMode;
+typedef enum { KSP_DMACTIVE_OPERATOR = 1, KSP_DMACTIVE_RHS = 2, KSP_DMACTIVE_INITIAL_GUESS = 4 } KSPDMActive;
+#define PCSHELL "shell"
 typedef const char *MatType;
 typedef const char *PCType;
 typedef enum { SOR_FORWARD_SWEEP = 1, SOR_BACKWARD_SWEEP = 2, SOR_SYMMETRIC_SWEEP = 3, SOR_LOCAL_FORWARD_SWEEP = 4 } MatSORType;
@@ -132,6 +155,50 @@ PetscErrorCode PetscOptionsGetBool(PetscOptions, const char[], const char[], Pet
 PetscErrorCode PetscViewerASCIIPrintf(PetscViewer, const char[], ...);
 PetscErrorCode PetscRandomGetSeed(PetscRandom, PetscInt64 *);
 PetscErrorCode PetscRandomDestroy(PetscRandom *);
+/* what the reference's examples ex3.c / ex5.c call besides the adapter's own needs (tests/test_adapter_syntax.py compiles them
+   UNCHANGED from /root/reference against these declarations and the MCSOR binding of adapter/mc_sor_hip.c) */
+PetscErrorCode PetscInitialize(int *, char ***, const char[], const char[]);
+PetscErrorCode PetscFinalize(void);
+PetscErrorCode PetscObjectSetName(PetscObject, const char[]);
+PetscErrorCode PetscViewerVTKOpen(MPI_Comm, const char[], PetscFileMode, PetscViewer *);
+PetscErrorCode PetscViewerDestroy(PetscViewer *);
+PetscErrorCode DMDACreate2d(MPI_Comm, DMBoundaryType, DMBoundaryType, DMDAStencilType, PetscInt, PetscInt, PetscInt, PetscInt, PetscInt, PetscInt, const PetscInt[], const PetscInt[], DM *);
+PetscErrorCode DMSetFromOptions(DM);
+PetscErrorCode DMSetUp(DM);
+PetscErrorCode DMDestroy(DM *);
+PetscErrorCode DMDASetUniformCoordinates(DM, PetscReal, PetscReal, PetscReal, PetscReal, PetscReal, PetscReal);
+PetscErrorCode DMCreateMatrix(DM, Mat *);
+PetscErrorCode DMCreateGlobalVector(DM, Vec *);
+PetscErrorCode KSPCreate(MPI_Comm, KSP *);
+PetscErrorCode KSPDestroy(KSP *);
+PetscErrorCode KSPSetOperators(KSP, Mat, Mat);
+PetscErrorCode KSPSetDM(KSP, DM);
+PetscErrorCode KSPSetDMActive(KSP, KSPDMActive, PetscBool);
+PetscErrorCode KSPSetFromOptions(KSP);
+PetscErrorCode KSPSetUp(KSP);
+PetscErrorCode KSPSetInitialGuessNonzero(KSP, PetscBool);
+PetscErrorCode KSPSolve(KSP, Vec, Vec);
+PetscErrorCode PCShellSetApply(PC, PetscErrorCode (*)(PC, Vec, Vec));
+PetscErrorCode PCShellSetContext(PC, void *);
+PetscErrorCode PCShellGetContext(PC, void *);
+PetscErrorCode MatCreateLRC(Mat, Mat, Vec, Mat, Mat *);
+PetscErrorCode MatMult(Mat, Vec, Vec);
+PetscErrorCode MatDestroy(Mat *);
+PetscErrorCode MatDuplicate(Mat, MatDuplicateOption, Mat *);
+PetscErrorCode MatDenseGetColumnVecWrite(Mat, PetscInt, Vec *);
+PetscErrorCode MatDenseRestoreColumnVecWrite(Mat, PetscInt, Vec *);
+PetscErrorCode MatDenseGetArrayWrite(Mat, PetscScalar **);
+PetscErrorCode MatDenseRestoreArrayWrite(Mat, PetscScalar **);
+PetscErrorCode ISColoringCreate(MPI_Comm, PetscInt, PetscInt, const ISColoringValue[], PetscCopyMode, ISColoring *);
+PetscErrorCode ISColoringSetType(ISColoring, ISColoringType);
+PetscErrorCode ISColoringDestroy(ISColoring *);
+PetscErrorCode VecSetRandom(Vec, PetscRandom);
+PetscErrorCode VecDuplicate(Vec, Vec *);
+PetscErrorCode VecCopy(Vec, Vec);
+PetscErrorCode VecAXPY(Vec, PetscScalar, Vec);
+PetscErrorCode VecNorm(Vec, NormType, PetscReal *);
+PetscErrorCode VecView(Vec, PetscViewer);
+PetscErrorCode VecGetOwnershipRange(Vec, PetscInt *, PetscInt *);
 /* Vec */
 PetscErrorCode VecGetLocalSize(Vec, PetscInt *);
 PetscErrorCode VecZeroEntries(Vec);

@@ -17,7 +17,8 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 ADAPTER = ROOT / "adapter"
-FILES = [ADAPTER / "pc_hipgibbs.c", ADAPTER / "pc_hipgamgmc.c", ADAPTER / "pc_hipparsor.c", ADAPTER / "pc_hipwoodbury.c"]
+FILES = [ADAPTER / "pc_hipgibbs.c", ADAPTER / "pc_hipgamgmc.c", ADAPTER / "pc_hipparsor.c", ADAPTER / "pc_hipwoodbury.c", ADAPTER / "mc_sor_hip.c"]
+REFERENCE = Path("/root/reference")  # present in the build container only; never on the GPU box
 GCC = shutil.which("gcc")
 INC = ["-I", str(ROOT / "tests" / "petsc_decl_mock"), "-I", str(ROOT / "include"), "-I", "/opt/rocm/include", "-I", str(ADAPTER), "-D__HIP_PLATFORM_AMD__"]
 
@@ -81,6 +82,50 @@ def test_constructors_fill_the_ops_of_the_reference_constructors():
         assert opt in gibbs
     for opt in ("-pc_gamgmc_mg_type", "-mg_levels_ksp_max_it", "-mg_coarse_pc_type", "-mg_levels_pc_type", "-pc_mg_galerkin"):
         assert opt in mg
+
+
+def test_mcsor_binding_and_the_reference_option_keys():
+    """round 4: the ten functions of reference include/parmgmc/mc_sor.h:21-30 with their PETSc types (adapter/mc_sor_hip.c),
+    -mc_sor_omega (src/mc_sor.c:638), the cholsampler's option keys (src/pc_chols.c:415-417), and an ERROR for the one
+    option that has no device form (-pc_sorgibbs_local_forward, src/pc_sorgibbs.c:274)"""
+    mc = (ADAPTER / "mc_sor_hip.c").read_text()
+    for fn in ("MCSORCreate(Mat A, MCSOR *m)", "MCSORSetUp(MCSOR m)", "MCSORDestroy(MCSOR *m)", "MCSORApply(MCSOR m, Vec b, Vec y)", "MCSORSetOmega(MCSOR m, PetscReal omega)", "MCSORSetSweepType(MCSOR m, MatSORType type)", "MCSORGetSweepType(MCSOR m, MatSORType *type)",
+               "MCSORGetISColoring(MCSOR m, ISColoring *isc)", "MCSORGetNumColors(MCSOR m, PetscInt *colors)", "MCSORBuildLRCCorrection(PetscErrorCode (*det_sor)(void *, Vec, Vec), void *ctx, Mat Asor, Mat B, Vec S, Mat *Bb)"):
+        assert "PetscErrorCode " + fn in mc, fn
+    assert '"-mc_sor_omega"' in mc and "pmg_mcsor_apply(" in mc and "pmg_distmcsor_apply(" in mc and "pmg_rowblock_sampler_create(" in mc
+    assert "pmg_mcsor_set_lowrank(" in mc and "pmg_distmcsor_set_lowrank(" in mc and "pmg_mcsor_get_coloring(" in mc and "ISColoringCreate(" in mc
+    gibbs = (ADAPTER / "pc_hipgibbs.c").read_text()
+    chol = gibbs[gibbs.index("static PetscErrorCode PCSetFromOptions_HipChol"):]
+    assert '"-pc_cholsampler_dense_threshold"' in chol and '"-pc_cholsampler_coarse_gamg"' in chol and "pc->ops->setfromoptions  = PCSetFromOptions_HipChol" in chol
+    lf = gibbs[gibbs.index('"-pc_sorgibbs_local_forward"'):]
+    assert "PETSC_ERR_SUP" in lf[:900]
+
+
+@pytest.mark.parametrize("idx", ["32", "64"])
+def test_mcsor_binding_matches_the_reference_header(idx):
+    """adapter/mc_sor_hip.c compiled with the REFERENCE's own <parmgmc/mc_sor.h> and <parmgmc/parmgmc.h> in front of the
+    declaration mock: a definition that disagrees with the reference's prototype is a compile error (read in place under
+    /root/reference; nothing of it is in this repository)"""
+    if not GCC or not (REFERENCE / "include" / "parmgmc" / "mc_sor.h").exists():
+        pytest.skip("needs gcc and /root/reference (build container only)")
+    extra = ["-DPETSC_DECL_MOCK_64BIT_INDICES"] if idx == "64" else []
+    r = subprocess.run([GCC, "-std=gnu11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-DPARMGMC_HIP_HAVE_PETSC", *extra, "-I", str(REFERENCE / "include"), *INC, str(ADAPTER / "mc_sor_hip.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("example", ["ex3.c", "ex5.c"])
+def test_reference_examples_compile_unchanged_against_the_binding(example):
+    """examples/ex3.c (MCSOR inside a PCSHELL: the route BASELINE's north star names) and examples/ex5.c (symmetric =
+    forward o backward) of the reference, UNCHANGED, read in place: valid C against the reference's own parmgmc headers +
+    the PETSc declaration mock, i.e. every MCSOR* / PETSc call they make has the signature the binding and the mock declare"""
+    src = REFERENCE / "examples" / example
+    if not GCC or not src.exists():
+        pytest.skip("needs gcc and /root/reference (build container only)")
+    r = subprocess.run([GCC, "-std=gnu11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I", str(REFERENCE / "include"), "-I", str(ROOT / "tests" / "petsc_decl_mock"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    calls = set(re.findall(r"\b(MCSOR[A-Za-z]+)\(", src.read_text()))
+    binding = (ADAPTER / "mc_sor_hip.c").read_text()
+    assert calls and all(f"PetscErrorCode {c}(" in binding for c in calls), calls
 
 
 def test_adapter_calls_only_exported_c_abi_functions():
