@@ -22,6 +22,8 @@
 #include <petscvec.h>
 #include <parmgmc/parmgmc.h> /* PCRegisterSetSampleCallback, ParMGMCGetPetscRandom, PetscOptionItems_ARG, MULTICOL_SOR */
 #include <hip/hip_runtime_api.h>
+#include <stdlib.h>
+#include <string.h>
 #include <parmgmc_hip.h>
 
 /* PetscCall for the C-ABI: its status codes ARE PetscErrorCode numbers (include/parmgmc_hip.h), the text comes along */
@@ -153,7 +155,25 @@ static inline PetscErrorCode HipNoiseSeed(uint64_t stream_id, uint64_t *seed)
 /* the byte all-gather the library's row-block set-up calls back into (pmg_host_comm, include/parmgmc_hip.h) */
 static inline int HipMPIAllgather(void *ctx, const void *send, int64_t nbytes, void *recv)
 {
-  return MPI_Allgather((void *)send, (int)nbytes, MPI_BYTE, recv, (int)nbytes, MPI_BYTE, *(MPI_Comm *)ctx) == MPI_SUCCESS ? 0 : 1;
+  /* MPI counts are ints: blocks of 2 GiB and more go in pieces of 1 GiB (the library pads every rank's block to the same
+     length, so a large exchange of triples in the set-up of a hierarchy can get there); a piece lands at its place in
+     every rank's slot of recv.  Never a silently truncated count. */
+  const int64_t piece = (int64_t)1 << 30;
+  MPI_Comm      comm  = *(MPI_Comm *)ctx;
+  int           np    = 1;
+  if (nbytes < 0) return 1;
+  if (nbytes <= piece) return MPI_Allgather((void *)send, (int)nbytes, MPI_BYTE, recv, (int)nbytes, MPI_BYTE, comm) == MPI_SUCCESS ? 0 : 1;
+  if (MPI_Comm_size(comm, &np) != MPI_SUCCESS) return 1;
+  char *tmp = (char *)malloc((size_t)piece * (size_t)np);
+  if (!tmp) return 1;
+  int rc = 0;
+  for (int64_t off = 0; off < nbytes && !rc; off += piece) {
+    const int64_t len = nbytes - off < piece ? nbytes - off : piece;
+    rc                = MPI_Allgather((const char *)send + off, (int)len, MPI_BYTE, tmp, (int)len, MPI_BYTE, comm) == MPI_SUCCESS ? 0 : 1;
+    for (int r = 0; r < np && !rc; ++r) memcpy((char *)recv + (size_t)r * (size_t)nbytes + (size_t)off, tmp + (size_t)r * (size_t)len, (size_t)len);
+  }
+  free(tmp);
+  return rc;
 }
 
 /* *store must outlive hc (it is what hc->ctx points to) */

@@ -125,20 +125,38 @@ static PetscErrorCode HipSeqAIJArrays(Mat A, const char *what, PetscInt l, const
    14-75: off-diagonals -h2, diagonal kappa^2 + (#neighbours) h2, h2 = 1/(nx-1)^2)?  Then the hierarchy is the library's own
    DMDA hierarchy on z-slabs (matrix-free fine level, class-stencil Galerkin levels: pmg_mgmc_create_dmda_slab) and *kappa
    is read off the first local row.  Every rank checks ALL its rows; the verdict is agreed with an all-reduce. */
-static PetscErrorCode HipDetectDMDASlab(PC pc, Mat A, PetscBool *yes, PetscInt dims[3], PetscInt *zs, PetscInt *zm, PetscReal *kappa)
+static PetscErrorCode HipDetectDMDASlab(PC pc, PC mg, PetscInt levels, Mat A, PetscBool *yes, PetscInt dims[3], PetscInt *zs, PetscInt *zm, PetscReal *kappa)
 {
   PetscBool       isda = PETSC_FALSE;
   PetscInt        dim, M, N, P, m, n, p, dof, sw, xs, ys, xm, ym, rstart, rend;
   PetscMPIInt     ok = 1, all = 0;
   DMDAStencilType st;
+  DMBoundaryType  bx, by, bz;
 
   PetscFunctionBeginUser;
   *yes = PETSC_FALSE;
   if (pc->dm) PetscCall(PetscObjectTypeCompare((PetscObject)pc->dm, DMDA, &isda));
   if (!isda) ok = 0;
   if (ok) {
-    PetscCall(DMDAGetInfo(pc->dm, &dim, &M, &N, &P, &m, &n, &p, &dof, &sw, NULL, NULL, NULL, &st));
-    if (dim != 3 || dof != 1 || m != 1 || n != 1 || ((M - 1) % 2) || ((N - 1) % 2) || ((P - 1) % 2)) ok = 0;
+    PetscCall(DMDAGetInfo(pc->dm, &dim, &M, &N, &P, &m, &n, &p, &dof, &sw, &bx, &by, &bz, &st));
+    if (dim != 3 || dof != 1 || m != 1 || n != 1) ok = 0;
+    /* The slab path REPLACES PETSc's PCMG hierarchy with the library's own (Q1 interpolation between vertex grids
+       n -> (n-1)/2+1, R = P^T, Galerkin coarse operators), while the one-rank path hands over the level matrices PETSc
+       actually built.  So that the same options mean the same sampler on 1 and on N ranks, the path is taken only where
+       PETSc's hierarchy IS that one: star stencil of width 1 without periodic / ghosted boundaries, Q1 interpolation
+       (DMDA's default; -da_interp_type q0 would be piecewise constant), Galerkin coarse operators, and extents that halve
+       (levels - 1) times.  Anything else goes to the general row-block path (HipGAMGMCRowBlocks), which uses PETSc's own
+       level matrices -- advisor finding, round 3. */
+    if (ok) {
+      DMDAInterpolationType itype;
+      PCMGGalerkinType      gal;
+      const PetscInt        div = (PetscInt)1 << (levels > 1 ? levels - 1 : 0);
+      PetscCall(DMDAGetInterpolationType(pc->dm, &itype));
+      PetscCall(PCMGGetGalerkin(mg, &gal));
+      if (st != DMDA_STENCIL_STAR || sw != 1 || bx != DM_BOUNDARY_NONE || by != DM_BOUNDARY_NONE || bz != DM_BOUNDARY_NONE) ok = 0;
+      if (itype != DMDA_Q1 || gal == PC_MG_GALERKIN_NONE) ok = 0;
+      if (levels < 1 || ((M - 1) % div) || ((N - 1) % div) || ((P - 1) % div)) ok = 0;
+    }
   }
   if (ok) {
     const PetscReal h2 = 1.0 / (PetscReal)((M - 1) * (M - 1));
@@ -294,7 +312,7 @@ static PetscErrorCode PCSetUp_HipGAMGMC(PC pc)
     PetscReal kappa;
 
     PetscCall(HipHostComm(PetscObjectComm((PetscObject)pc), &pg->hc_comm, &pg->hc));
-    if (strcmp(pg->mgtype, PCMG) == 0) PetscCall(HipDetectDMDASlab(pc, P, &slab, dims, &zs, &zm, &kappa));
+    if (strcmp(pg->mgtype, PCMG) == 0) PetscCall(HipDetectDMDASlab(pc, pg->mg, levels, P, &slab, dims, &zs, &zm, &kappa));
     if (slab) { /* DMDA split in z: the library's own hierarchy on z-slabs, halo exchange over xGMI */
       int32_t *cuts, z0 = (int32_t)zs;
       PetscCall(PetscMalloc1((size_t)size + 1, &cuts));

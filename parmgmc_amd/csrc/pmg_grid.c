@@ -65,7 +65,7 @@ pmg_status pmg_grid_create(int32_t nx, int32_t ny, int32_t nzg, int32_t kz0, int
   g->L.kz0 = kz0;
   g->L.nzg = nzg;
   g->L.sx  = pmg_grid_line_stride(nx, ny, nzg);
-  g->L.sp  = (int64_t)ny * g->L.sx + (getenv("PMG_GRID_SP_PAD") ? atoll(getenv("PMG_GRID_SP_PAD")) : 0); /* experiment: pad doubles behind every plane */
+  g->L.sp  = (int64_t)ny * g->L.sx; /* (round 3's PMG_GRID_SP_PAD experiment -- planes shifted off their alignment, tools/alignbench.py -- is gone from the production build: an odd value misaligned every 16-byte access) */
   g->L.cs  = (int64_t)(nz + 2) * g->L.sp;
   g->kappa = kappa;
   g->h2    = 1. / ((nx - 1) * (nx - 1)); /* integer product, then the divide: src/problems.c:24 */

@@ -61,6 +61,7 @@ pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream);
 pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc l_fine, pmg_lrc l_coarse, const double *x_fine_lay, double *b_coarse_lay, void *stream);
 int        pmg_lrc_is_local(pmg_lrc l);
+void       pmg_lrc_get_sizes(pmg_lrc l, int32_t *k, int64_t *ns, int *dense); /* ns = 0: none of B's support on this rank */
 pmg_status pmg_lrc_get_compact(pmg_lrc l, int32_t *k, int64_t *ns, int64_t *rows_host, double *B_host, double *Bbf_host, double *Bbb_host);
 pmg_lrc    pmg_grid_lrc(pmg_grid g); /* the grid operator's low-rank update, NULL if none (borrowed) */
 void       pmg_lrc_destroy(pmg_lrc *l);

@@ -345,6 +345,17 @@ pmg_status pmg_lrc_get_compact(pmg_lrc l, int32_t *k, int64_t *ns, int64_t *rows
   return PMG_SUCCESS;
 }
 
+/* what a directional sweep touches of this update on THIS rank: the rank k and the number of rows its passes run over --
+   the support rows of the row-compact form, all ld rows of the dense form (*dense = 1), none (ns = 0) for a rank whose rows
+   miss B's support altogether (row-distributed operator).  A plain query: it cannot fail and leaves no error message. */
+void pmg_lrc_get_sizes(pmg_lrc l, int32_t *k, int64_t *ns, int *dense)
+{
+  const int is_dense = l && !l->empty && l->ns == 0;
+  if (k) *k = l ? l->k : 0;
+  if (ns) *ns = !l || l->empty ? 0 : (l->ns ? l->ns : l->ld);
+  if (dense) *dense = is_dense;
+}
+
 /* 1: the update lives on one device (no reduction over ranks, rows on this rank) */
 int pmg_lrc_is_local(pmg_lrc l) { return l && !l->reduce && !l->empty; }
 

@@ -1780,10 +1780,11 @@ pmg_status pmg_mgmc_get_algorithmic_bytes(pmg_mgmc h, double *total, double *per
     pmg_lrc         lr = Lv->is_grid ? (Lv->lrc ? Lv->lrc : pmg_grid_lrc(Lv->g)) : Lv->lrc;
     int32_t         k  = 0;
     int64_t         ns = 0;
-    if (lr && pmg_lrc_get_compact(lr, &k, &ns, NULL, NULL, NULL, NULL)) { /* dense factors: every row */
-      k  = h->lrc_k;
-      ns = (int64_t)N;
-    }
+    int             lr_dense = 0;
+    /* a rank whose slab or block misses B's support launches none of the low-rank kernels: ns = 0, no bytes (round 3 charged
+       such a rank the dense form's (24k + 48) N per sweep and inflated the summed roofline of the multi-GPU low-rank line) */
+    if (lr) pmg_lrc_get_sizes(lr, &k, &ns, &lr_dense);
+    if (lr_dense) ns = (int64_t)N; /* dense factors: every row of the level */
     const double sweep = Lv->is_grid ? (h->omega == 1.0 ? 24.0 : 32.0) * N : (Lv->is_st27 ? 24.0 * N : 12.0 * (double)Lv->A_nnz + 40.0 * N);
     const double lrsw  = lr ? ((8.0 * k + 24.0) + (16.0 * k + 24.0)) * (double)ns : 0.0;
     if (l == 0) {
@@ -1803,7 +1804,9 @@ pmg_status pmg_mgmc_get_algorithmic_bytes(pmg_mgmc h, double *total, double *per
       if (lr) {
         int32_t kc = 0;
         int64_t nc = 0;
-        if (fused && Cc->lrc && !pmg_lrc_get_compact(Cc->lrc, &kc, &nc, NULL, NULL, NULL, NULL)) by += (8.0 * k + 8.0) * (double)ns + (8.0 * k + 16.0) * (double)nc;
+        int     cdense = 0;
+        if (Cc->lrc) pmg_lrc_get_sizes(Cc->lrc, &kc, &nc, &cdense);
+        if (fused && Cc->lrc && !cdense) by += (8.0 * k + 8.0) * (double)ns + (8.0 * k + 16.0) * (double)nc;
         else by += (8.0 * k + 8.0) * (double)ns + (8.0 * k + 16.0) * (double)ns;
       }
       const int one_colour = Lv->is_grid && h->omega == 1.0 && h->nu >= 1 && !getenv("PMG_MG_PROLONG_BOTH");

@@ -367,6 +367,43 @@ pmg_status pmg_rowblock_plan_get(pmg_rowblock_plan p, int32_t *nghost, const int
   return PMG_SUCCESS;
 }
 
+/* A colouring is only usable if no owned row shares its colour with one of its columns -- owned or ghost (the ghost rows'
+   colours are in the plan: a ghost row is received in the colour in which it changes).  Rows swept together would otherwise
+   read each other's half-updated values and the chain would be wrong without any other symptom, so every constructor that
+   takes rows + a plan checks it (cheap: one pass over the rows).  rp / ci: the owned rows with GLOBAL columns.  Local. */
+static pmg_status rowblock_check_coloring(const pmg_rowblock_plan p, const int64_t *rp, const int64_t *ci, const int32_t *colors_owned)
+{
+  const int64_t nloc = p->nloc, r0 = p->row0;
+  int32_t      *gcol = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->nghost > 0 ? p->nghost : 1));
+  PMG_CHECK(gcol, PMG_ERR_MEM, "out of host memory");
+  for (int32_t q = 0; q < p->nghost; ++q) gcol[q] = -1;
+  for (int32_t c = 0; c < p->ncolors; ++c)
+    for (int64_t w = p->recv_ptr[c]; w < p->recv_ptr[c + 1]; ++w) gcol[p->recv_rows[w] - nloc] = c;
+  pmg_status st = PMG_SUCCESS;
+  for (int64_t i = 0; i < nloc && !st; ++i)
+    for (int64_t k = rp[i]; k < rp[i + 1] && !st; ++k) {
+      const int64_t c = ci[k];
+      if (c == r0 + i) continue;
+      int32_t cc;
+      if (c >= r0 && c < r0 + nloc) cc = colors_owned[c - r0];
+      else {
+        const int64_t q = bsearch_i64(p->ghosts, p->nghost, c);
+        cc              = q >= 0 ? gcol[q] : -1;
+      }
+      if (cc == colors_owned[i]) st = pmg_set_error(PMG_ERR_ARG_WRONG, __FILE__, __LINE__, "not a distance-1 colouring: rows %lld and %lld are coupled and both have colour %d", (long long)(r0 + i), (long long)c, (int)cc);
+    }
+  free(gcol);
+  return st;
+}
+
+/* the same check for a caller that holds rows and a plan (collective: a conflict on one rank is returned on every rank) */
+pmg_status pmg_rowblock_check_coloring(const pmg_host_comm *comm, pmg_rowblock_plan plan, const int64_t *rowptr, const int64_t *colidx_global, const int32_t *colors_owned)
+{
+  PMG_CALL(hc_check(comm));
+  PMG_CHECK(plan && rowptr && (plan->nloc == 0 || (colidx_global && colors_owned)), PMG_ERR_ARG_NULL, "null argument");
+  return hc_agree(comm, rowblock_check_coloring(plan, rowptr, colidx_global, colors_owned), "checking the colouring");
+}
+
 /* ---------------------------------------------------------------------------------------------------- */
 /* first-fit colouring of the global matrix, rank after rank                                              */
 /* ---------------------------------------------------------------------------------------------------- */
@@ -400,19 +437,26 @@ pmg_status pmg_rowblock_color_greedy(const pmg_host_comm *comm, const int64_t *r
   int32_t nc = 0;
   for (int r = 0; r < np && !st; ++r) {
     if (r == me) {
-      mark = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nloc + 2));
+      /* First fit gives a row a colour that is at most the number of its neighbours, whatever colours those carry: the
+         mark array is sized by the largest row, NOT by the number of local rows (round 3 sized it nloc + 2 and dropped
+         neighbour colours above nloc -- a block of one or two rows beside a clique of a lower rank could then repeat a
+         neighbour's colour: advisor finding, reproduced by tests/test_rowblock_c.py::test_tiny_block_beside_a_clique) */
+      int64_t maxdeg = 0;
+      for (int64_t i = 0; i < nloc; ++i)
+        if (rp[i + 1] - rp[i] > maxdeg) maxdeg = rp[i + 1] - rp[i];
+      mark = (int32_t *)malloc(sizeof(int32_t) * (size_t)(maxdeg + 2));
       if (!mark) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
-      for (int64_t i = 0; i <= nloc && !st; ++i) mark[i] = -1;
-      for (int64_t i = 0; i < nloc && !st; ++i) { /* a row has at most nloc + (lower) neighbours; colours stay below its degree + 1 */
+      for (int64_t i = 0; i <= maxdeg + 1 && !st; ++i) mark[i] = -1;
+      for (int64_t i = 0; i < nloc && !st; ++i) {
         for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
           const int64_t c = ci[k];
           int32_t       cc = -1;
           if (c < r0) cc = lcol[bsearch_i64(low, nlow, c)];
           else if (c < r0 + i) cc = colors_owned[c - r0];
-          if (cc >= 0 && cc <= nloc) mark[cc] = (int32_t)i;
+          if (cc >= 0 && cc <= maxdeg) mark[cc] = (int32_t)i; /* a colour above the row's degree cannot be the smallest free one */
         }
         int32_t col = 0;
-        while (col <= nloc && mark[col] == (int32_t)i) ++col;
+        while (col <= maxdeg && mark[col] == (int32_t)i) ++col;
         colors_owned[i] = col;
         if (col + 1 > nc) nc = col + 1;
       }
@@ -817,6 +861,7 @@ pmg_status pmg_rbh_build(pmg_rbh h)
     }
     st = hc_agree(c, st, "collecting the rows the transfers read");
     if (!st) st = pmg_rowblock_plan_create(c, Lv->starts, Lv->A.rp[Lv->nloc], Lv->A.ci, nx, extra, Lv->ncolors, Lv->colors, &Lv->plan);
+    if (!st) st = hc_agree(c, rowblock_check_coloring(Lv->plan, Lv->A.rp, Lv->A.ci, Lv->colors), "checking the colouring of a level");
     free(extra);
   }
   /* ---- local matrices ---- */
@@ -978,6 +1023,7 @@ pmg_status pmg_rowblock_sampler_create(const pmg_host_comm *comm, pmg_dist trans
     colors_owned = cols;
   }
   if (!st) st = pmg_rowblock_plan_create(comm, row_starts, A.rp[nloc], A.ci, 0, NULL, ncolors, colors_owned, &plan);
+  if (!st) st = hc_agree(comm, rowblock_check_coloring(plan, A.rp, A.ci, colors_owned), "checking the colouring");
   if (!st) { /* local operator */
     const int32_t ng = plan->nghost;
     const int64_t nnz = A.rp[nloc], nl = nloc + ng;
@@ -1082,13 +1128,18 @@ pmg_status pmg_dist_create_comm(const pmg_host_comm *comm, const char *kind, pmg
     st = hc_agree(comm, st, "ipc: opening the peers' memory handles"); /* also the barrier in front of the first message */
   } else st = pmg_set_error(PMG_ERR_ARG_OUTOFRANGE, __FILE__, __LINE__, "transport '%s' (ipc | rccl)", kind);
   if (st) {
-    if (d) { /* every rank got here together (agreement above): orderly tear-down */
-      int32_t z = 0, *all = (int32_t *)malloc(sizeof(int32_t) * (size_t)np);
-      pmg_dist_ipc_disconnect(d);
+    /* Every rank gets here together (each branch ends in an agreement), but NOT every rank holds an object: the creation
+       may have failed on some ranks only.  The barrier all-gather between "peers' blocks unmapped" and "own block freed"
+       is therefore entered by every rank, with or without an object (round 3 guarded it by `if (d)`: the ranks whose
+       creation had failed skipped a collective the others entered -- advisor finding); only the calls on the object are
+       conditional.  An unknown `kind` fails identically everywhere before any collective and needs none. */
+    if (strcmp(kind, "ipc") == 0 || strcmp(kind, "rccl") == 0) {
+      int32_t z = 0, small[64], *all = np <= 64 ? small : (int32_t *)malloc(sizeof(int32_t) * (size_t)np);
+      if (d) pmg_dist_ipc_disconnect(d);
       if (all) hc_allgather(comm, &z, sizeof z, all);
-      free(all);
-      pmg_dist_destroy(&d);
+      if (all != small) free(all);
     }
+    if (d) pmg_dist_destroy(&d);
     return st;
   }
   *out = d;

@@ -520,3 +520,66 @@ def test_a_chain_of_ipc_objects_in_one_process_reuses_its_receive_block():
         one.sample(torch.as_tensor(b_all, device="cuda"), yd, sweeps, seed=42, counter0=1)
         got = np.concatenate([x[1][it] for x in parts])
         assert np.array_equal(got, yd.cpu().numpy()), f"object {it} of the chain"
+
+
+def _bytes_worker(rank, world, port, grid, levels, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PMG_MG_REPLICATE_BELOW"] = "400"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from parmgmc_amd.capi import lib
+    from parmgmc_amd.dist import DistMGMC
+
+    nx, ny, nz = grid
+    out = {}
+    for lowrank in (False, True):
+        mg = DistMGMC(nx, ny, nz, 1.5, levels, rank, world, transport="ipc")
+        mg.set_smoother(True, 1.0, 1, 1)
+        lo, hi = mg.plane_range[0] * nx * ny, mg.plane_range[1] * nx * ny
+        if lowrank:  # ONE ball well inside the first slab: the second rank holds none of B's support
+            X, Y, Z = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), np.linspace(0, 1, nz), indexing="ij")
+            pts = np.stack([X.ravel(order="F"), Y.ravel(order="F"), Z.ravel(order="F")], 1)
+            inside = ((pts - np.asarray((0.5, 0.5, 0.15))) ** 2).sum(1) < 0.1 ** 2
+            B = np.zeros((nx * ny * nz, 1))
+            B[inside, 0] = 1.0 / inside.sum()
+            assert not inside[nx * ny * (nz // 2 - 2):].any()
+            mg.set_lowrank(B[lo:hi], np.array([50.0]))
+        mg.setup()
+        y = torch.zeros(hi - lo, dtype=torch.float64, device="cuda")
+        mg.sample(torch.ones(hi - lo, dtype=torch.float64, device="cuda"), y, 2, seed=3, counter0=0)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y).all())
+        out[lowrank] = (mg.algorithmic_bytes()[1][-1], lib.pmg_last_error_string().decode())  # the (distributed) finest level
+        mg.destroy()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_slab_without_observations_is_charged_no_lowrank_bytes():
+    """advisor (round 3): pmg_mgmc_get_algorithmic_bytes charged a rank whose slab misses B's support the DENSE form's
+    (24 k + 48) N bytes per sweep (and left a stale error message): bench.py sums the ranks' bytes into the roofline of the
+    multi-GPU low-rank line.  Two z-slabs, one ball inside the first: the second rank's finest level must count exactly
+    the bytes of the plain cycle, the first rank's a little more."""
+    import torch.multiprocessing as mp
+
+    grid, levels, world = (17, 17, 33), 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bytes_worker, args=(r, world, port, grid, levels, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    plain0, with0 = parts[0][False][0], parts[0][True][0]
+    plain1, with1 = parts[1][False][0], parts[1][True][0]
+    assert with1 == plain1, (plain1, with1)          # no support on rank 1: nothing launched, nothing charged
+    assert plain0 < with0 < 1.5 * plain0, (plain0, with0)  # rank 0: a few support rows, far from the dense form
+    assert "dense" not in parts[1][True][1]          # and the query is not routed through the error path

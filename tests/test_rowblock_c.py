@@ -186,3 +186,75 @@ def test_c_plans_equal_the_python_plans(world, idx_width):
         p.join(timeout=60)
     for r, msg in sorted(res):
         assert msg == "ok", f"rank {r}:\n{msg}"
+
+
+def _clique_worker(rank, world, port, q):
+    """rank 0 owns a K4 clique (rows 0..3, colours 0..3) and a fifth row; rank 1 owns ONE row coupled to rows 0, 1, 2 and to
+    nothing else: first fit must give it colour 3.  Round 3 sized its mark array by the number of LOCAL rows (1 + 2 slots),
+    dropped the neighbour colour 2 and handed out colour 2 -- the colour of its neighbour row 2 (advisor finding)."""
+    import torch.distributed as dist
+
+    from parmgmc_amd import capi
+    from parmgmc_amd.capi import check, lib
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm, keep = capi.torch_host_comm(rank, world)
+        n = 6
+        D = np.zeros((n, n))
+        for i in range(4):
+            for j in range(4):
+                D[i, j] = -1.0
+        D[4, 3] = D[3, 4] = -1.0  # rank 0's fifth row: a neighbour of row 3 only
+        for j in (0, 1, 2):
+            D[5, j] = D[j, 5] = -1.0  # rank 1's only row
+        D[np.arange(n), np.arange(n)] = 10.0
+        A = sp.csr_matrix(D)
+        A.sort_indices()
+        starts = np.array([0, 5, 6], np.int64)
+        r0, r1 = int(starts[rank]), int(starts[rank + 1])
+        mine = A[r0:r1].tocsr()
+        rp, ci, v = np.ascontiguousarray(mine.indptr, np.int64), np.ascontiguousarray(mine.indices, np.int64), np.ascontiguousarray(mine.data)
+        cols = np.full(r1 - r0, -7, np.int32)
+        nc = C.c_int32()
+        check(lib.pmg_rowblock_color_greedy(C.byref(comm), starts.ctypes.data, rp.ctypes.data, ci.ctypes.data, cols.ctypes.data, C.byref(nc)))
+        want = O.coloring_greedy(O.CSR.from_scipy(A))
+        assert np.array_equal(cols, want[r0:r1]), (rank, cols, want)
+        assert nc.value == int(want.max()) + 1 == 4
+        # the plan + the validity check behind every constructor: the right colouring passes, a colouring with the round-3
+        # fault (row 5 in the colour of its neighbour row 2) is refused ON EVERY RANK, although only rank 1 can see it
+        transport = None
+        for bad in (False, True):
+            c2 = cols.copy()
+            if bad and rank == 1:
+                c2[0] = 2
+            pl = C.c_void_p()
+            check(lib.pmg_rowblock_plan_create(C.byref(comm), starts.ctypes.data, len(ci), ci.ctypes.data, 0, None, 4, c2.ctypes.data, C.byref(pl)))
+            st = lib.pmg_rowblock_check_coloring(C.byref(comm), pl, rp.ctypes.data, ci.ctypes.data, c2.ctypes.data)
+            assert (st != 0) == bad, (rank, bad, st)
+            lib.pmg_rowblock_plan_destroy(C.byref(pl))
+        q.put((rank, "ok"))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tiny_block_beside_a_clique():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_clique_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for r, msg in sorted(res):
+        assert msg == "ok", f"rank {r}:\n{msg}"

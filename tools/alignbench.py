@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What costs the 2^k+1 grids their 15-17 % per point against 2^k?  The noisy sweep (ns per 1000 point updates) on boxes that
-are odd in one direction at a time; PMG_GRID_SP_PAD=<doubles> (read by pmg_grid_create) shifts the planes of any grid off
+are odd in one direction at a time; PMG_GRID_SP_PAD=<doubles> (read by pmg_grid_create up to round 3; removed from the production build in round 4) shifts the planes of any grid off
 their natural alignment.  Development tool; results in DESIGN.md section 9, item 5."""
 import os
 import sys
