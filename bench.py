@@ -550,8 +550,22 @@ def main() -> None:
         except Exception as e:  # noqa: BLE001
             err = err or f"{type(e).__name__}: {e}"
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        ranks = None
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            # a self-describing record: every rank says where it ran, whether its device reaches its
+            # z-neighbours' devices as peers, how long ITS timed region took and how often its face wavefronts had to poll
+            # for a halo flag; gathered to rank 0.  Under torchrun the neighbours' device indices are their local ranks
+            # (every process sees all devices of the node); with PMG_BENCH_SHARE_DEVICE all ranks sit on device 0.
+            try:
+                lo_dev = -1 if rank == 0 else (0 if share else local - 1)
+                hi_dev = -1 if rank == world - 1 else (0 if share else local + 1)
+                me = smp.describe(lo_dev, hi_dev)
+            except Exception as e:  # noqa: BLE001
+                me = {"rank": rank, "error": f"{type(e).__name__}: {e}"}
+            me.update({"local_rank": local, "timed_region_s": dt, "device_ms": dev_ms, "host": os.uname().nodename, "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")})
+            ranks = [None] * world
+            dist.all_gather_object(ranks, me)
         finite = bool(torch.isfinite(y).all().item())
         # multi-GPU only, outside the timed region: rank 0 repeats the whole chain on ITS device alone and compares its
         # slab bit for bit (the noise depends on global indices only, so the distributed chain must reproduce it exactly)
@@ -571,7 +585,7 @@ def main() -> None:
             torch.cuda.empty_cache()
         good = err is None and (halo_check is None or halo_check.startswith("bit-identical"))
         ok = agree(good)
-        return dict(smp=smp, g=g, y=y, b=b, dt=float(tmax.item()), dev_ms=dev_ms, finite=finite, halo_check=halo_check, settle=st, err=err, ok=ok, chain_len=ctr, timed_from=timed_from)
+        return dict(smp=smp, g=g, y=y, b=b, dt=float(tmax.item()), dev_ms=dev_ms, finite=finite, halo_check=halo_check, settle=st, err=err, ok=ok, chain_len=ctr, timed_from=timed_from, ranks=ranks)
 
     # N > 1: the transports in order of preference; one that fails at run time (lost flag, wrong halo data) is dropped
     # and the next one measured -- decided by rank 0's bit-for-bit check, agreed by all ranks
@@ -623,6 +637,13 @@ def main() -> None:
         }
         if halo_check is not None:
             out["halo_check"] = halo_check
+        if res.get("ranks"):
+            rk = res["ranks"]
+            ts = sorted(r.get("timed_region_s", float("nan")) for r in rk)
+            out["ranks_seen"] = {"torch_world_size": dist.get_world_size(), "records": len(rk), "rccl_comm_count": max((r.get("rccl_comm_count", 0) for r in rk), default=0), "distinct_devices": len({(r.get("host"), r.get("pci_bus_id")) for r in rk})}
+            out["timed_region_s"] = {"min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1]}
+            out["halo_wait_polls_total"] = sum(int(r.get("halo_wait_polls", 0)) for r in rk)
+            out["ranks"] = rk
         if len(tried) > 1:
             out["transports_tried"] = tried
         dog.out = out

@@ -219,6 +219,20 @@ static int run_rank(const pmg_host_comm *hc, int share, int n, double kappa, con
     barrier(hc);
     const double t = now() - t0;
     if (me == 0 && phase) printf("Sampling: %.6f s\nTime per sample [ms]: %.6f\n", t, t / n_samples * 1000);
+    if (phase) { /* the self-describing record of a multi-rank run, one line per rank in rank order (the same fields as
+                    bench.py's "ranks"): where the rank ran, whether its device reaches its z-neighbours' devices, its own time */
+      pmg_dist_description ds;
+      const int            mydev = share ? 0 : me % ndev;
+      CHK(pmg_dist_describe(d, me > 0 ? (share ? 0 : (me - 1) % ndev) : -1, me < np - 1 ? (share ? 0 : (me + 1) % ndev) : -1, &ds));
+      for (int r = 0; r < np; ++r) {
+        barrier(hc);
+        if (r == me) {
+          printf("rank %d/%d: device %d pci_bus_id %s transport %s neighbour_ranks [%d, %d] peer_access_lo_hi [%d, %d] rccl_comm_count %d halo_wait_polls %llu timed_region_s %.6f\n", ds.rank, ds.nranks, mydev, ds.pci_bus_id, ds.transport, ds.neighbour[0], ds.neighbour[1], ds.peer_access[0], ds.peer_access[1], ds.rccl_comm_count, (unsigned long long)ds.halo_wait_polls, t);
+          fflush(stdout);
+        }
+      }
+      barrier(hc);
+    }
   }
   if (!is_mg) {
     CHK(pmg_grid_from_cvec(g, yc, y, NULL));

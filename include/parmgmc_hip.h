@@ -236,6 +236,18 @@ pmg_status pmg_dist_allgather(pmg_dist d, double *buf_dev, const int64_t *offset
 pmg_status pmg_dist_check(pmg_dist d);
 /* rank / number of ranks / largest message (doubles) the generic exchange can carry */
 pmg_status pmg_dist_get_info(pmg_dist d, int32_t *rank, int32_t *nranks, int64_t *capacity);
+/* A rank's own description of where it runs and how its halos travel -- printed per rank by `bench.py --gpus N` and
+   `examples/pmg_bench -ranks N` so that a run on several physical GPUs can be judged from its record alone: device index
+   and PCI bus id, peer access to the z-neighbours' devices (lo_device / hi_device: their device indices as this process
+   sees them, -1 = no such neighbour; result 1 / 0 / -1 = yes / no / not applicable), the z-neighbours' ranks, the
+   transport ("ipc" | "rccl"), ncclCommCount of the RCCL communicator (0 on ipc), and the polls of halo flag words that
+   found them not yet raised since the object was created (ipc: 0 in steady state).  Synchronises the device. */
+typedef struct {
+  int32_t  rank, nranks, device, neighbour[2], peer_access[2], rccl_comm_count;
+  uint64_t halo_wait_polls;
+  char     pci_bus_id[32], transport[8];
+} pmg_dist_description;
+pmg_status pmg_dist_describe(pmg_dist d, int32_t lo_device, int32_t hi_device, pmg_dist_description *out);
 /* ipc transport: unmap the peers' receive blocks.  Orderly tear-down when further transports follow: every rank
    disconnects, the caller runs a barrier, every rank destroys (frees its own block). */
 pmg_status pmg_dist_ipc_disconnect(pmg_dist d);

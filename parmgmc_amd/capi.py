@@ -157,6 +157,7 @@ _sig = {
     "pmg_dist_allreduce_sum": (_int, [_vp, _vp, _i32, _vp]),
     "pmg_dist_check": (_int, [_vp]),
     "pmg_dist_get_info": (_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_int64)]),
+    "pmg_dist_describe": (_int, [_vp, _i32, _i32, _vp]),
     "pmg_mgmc_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_mgmc_set_correction_form": (_int, [_vp, _int]),
     "pmg_mgmc_set_fused_transfers": (_int, [_vp, _int]),
@@ -273,6 +274,16 @@ class HostComm(C.Structure):
     """pmg_host_comm: the byte all-gather the C set-up calls back into"""
 
     _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("allgather", ALLGATHER_FN), ("ctx", C.c_void_p)]
+
+
+class DistDescription(C.Structure):
+    """pmg_dist_description"""
+
+    _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32), ("neighbour", C.c_int32 * 2), ("peer_access", C.c_int32 * 2), ("rccl_comm_count", C.c_int32), ("halo_wait_polls", C.c_uint64), ("pci_bus_id", C.c_char * 32), ("transport", C.c_char * 8)]
+
+    def as_dict(self):
+        return {"rank": self.rank, "nranks": self.nranks, "device": self.device, "pci_bus_id": self.pci_bus_id.decode(errors="replace"), "neighbour_ranks": list(self.neighbour), "peer_access_lo_hi": list(self.peer_access),
+                "transport": self.transport.decode(errors="replace"), "rccl_comm_count": self.rccl_comm_count, "halo_wait_polls": int(self.halo_wait_polls)}
 
 
 class RbhLevelView(C.Structure):

@@ -95,7 +95,7 @@ __device__ __forceinline__ double table_at(const double (&a)[8], int idx)
 // one wavefront waits (lane 0 polls, the others follow) until *f >= v; gives up after ~90 s (2^28 polls: four ranks SHARING one GPU have been seen to keep a neighbour's kernel off the device for a minute; the shorter limit of round 1 turned that into an error).  The flag words and the
 // planes they announce live in FINE-GRAINED memory (never cached in L2), so relaxed polls and a plain ordering fence
 // are enough -- a system-scope acquire would invalidate the L2 under the interior sweep on every poll.
-__device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, unsigned *err)
+__device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, unsigned *err, unsigned long long *spin_total)
 {
   if (threadIdx.x == 0) {
     unsigned long long spins = 0;
@@ -113,6 +113,7 @@ __device__ __forceinline__ void wave_wait_flag(const uint64_t *f, uint64_t v, un
         break;
       }
     }
+    if (spins && spin_total) atomicAdd(spin_total, spins); /* only a wavefront that actually waited pays for the report */
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grid
     const int z = (int)blockIdx.z;
     k           = z == 0 ? 0 : (z == 1 ? L.nz - 1 : z - 1);
     const bool face_lo = k == 0, face_hi = k == L.nz - 1;
-    if (face_lo && halo.wlo) wave_wait_flag(halo.wlo, halo.wval, halo.err);
-    if (face_hi && halo.whi) wave_wait_flag(halo.whi, halo.wval, halo.err);
+    if (face_lo && halo.wlo) wave_wait_flag(halo.wlo, halo.wval, halo.err, halo.spins);
+    if (face_hi && halo.whi) wave_wait_flag(halo.whi, halo.wval, halo.err, halo.spins);
     grid_color_sweep_body<NOISY, OMEGA1, HALO, PACKED>(L, op, c, t, j, k, tab, tab_entry, halo, b_own, y_other, y_own);
     if (face_lo || face_hi) { // every block of a face plane reports; the last one tells the neighbours
       // the peer stores are system-scope write-through stores (st2_sys): waiting for their completion is all a

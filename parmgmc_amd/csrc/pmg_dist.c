@@ -45,6 +45,7 @@ typedef struct {
   int (*Recv)(void *, size_t, int, int, pmg_nccl_comm, hipStream_t);
   int (*GroupStart)(void);
   int (*GroupEnd)(void);
+  int (*CommCount)(pmg_nccl_comm, int *);
   const char *(*GetErrorString)(int);
 } pmg_rccl_api;
 
@@ -65,6 +66,7 @@ static pmg_status rccl_load(const char *path, pmg_rccl_api *api)
   PMG_SYM(Recv, "ncclRecv");
   PMG_SYM(GroupStart, "ncclGroupStart");
   PMG_SYM(GroupEnd, "ncclGroupEnd");
+  PMG_SYM(CommCount, "ncclCommCount");
   PMG_SYM(GetErrorString, "ncclGetErrorString");
 #undef PMG_SYM
   return PMG_SUCCESS;
@@ -102,6 +104,7 @@ struct pmg_dist_s {
   uint64_t      nthrottle;
   unsigned     *err_dev;               /* pinned host word (device-visible), set by a flag wait that gave up */
   unsigned     *xch_counter;           /* device: blocks of the push kernel that have finished */
+  unsigned long long *spins_dev;       /* device: polls of halo flag words that were not yet raised (pmg_dist_describe) */
   double       *red_buf;               /* device: nranks x 4096 partial sums of pmg_dist_allreduce_sum */
   /* all-peer mappings (optional, pmg_dist_ipc_connect_all): single-step all-gather.  Every block has, behind the
      generic slots, two gather areas (parity) of gcap doubles; flag word 8 + src announces rank src's block */
@@ -297,6 +300,8 @@ pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t rank, int32_t nranks, pmg_dis
   if (!st) memset(d->err_dev, 0, 8 * sizeof(unsigned));
   if (!st) st = pmg_dev_alloc((void **)&d->xch_counter, 2 * sizeof(unsigned)); /* [0] generic exchange, [1] face wavefronts */
   if (!st && hipMemset(d->xch_counter, 0, 2 * sizeof(unsigned)) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
+  if (!st) st = pmg_dev_alloc((void **)&d->spins_dev, sizeof(unsigned long long));
+  if (!st && hipMemset(d->spins_dev, 0, sizeof(unsigned long long)) != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "memset failed");
   if (st) {
     pmg_dist_destroy(&d);
     return st;
@@ -472,6 +477,7 @@ static pmg_status ipc_sample(pmg_dist d, const double *b, double *y, int32_t its
         h.sval    = d->round[c];
         h.counter = d->xch_counter + 1;
         h.err     = d->err_dev;
+        h.spins   = d->spins_dev;
         PMG_CALL(pmg_grid_sweep_color_halo_cvec(d->g, c, noisy, scaled, seed, ctr, &h, b, y, s));
       }
       if ((ctr & 1) == 1) PMG_CALL(ipc_throttle(d, s)); /* an event every other sweep: each one costs a marker on the stream */
@@ -536,6 +542,7 @@ pmg_status pmg_dist_destroy(pmg_dist *dp)
     pmg_dev_free(d->ag_flag_dev);
     if (d->err_dev) (void)hipHostFree(d->err_dev);
     pmg_dev_free(d->xch_counter);
+    pmg_dev_free(d->spins_dev);
     ipc_pool_put(d->block, d->block_pooled);
   }
   pmg_dev_free(d->red_buf);
@@ -699,6 +706,46 @@ pmg_status pmg_dist_check(pmg_dist d)
 {
   PMG_CHECK(d, PMG_ERR_ARG_NULL, "null dist object");
   return d->transport == 1 ? ipc_check(d) : PMG_SUCCESS;
+}
+
+/* What a multi-GPU run should say about itself (bench.py --gpus N and examples/pmg_bench -ranks N print it per rank, so that
+   the first run on more than one physical GPU can be read whatever it shows): the device this rank computes on, its PCI bus
+   id, whether the device can access the devices `lo_device` / `hi_device` of its z-neighbours as peers (-1: no such
+   neighbour; the caller knows the neighbours' device indices -- the local ranks under torchrun), the transport, the size of
+   the RCCL communicator as RCCL itself counts it (0 for the ipc transport), and the polls of halo flag words that found
+   them not yet raised since the object was created (ipc; synchronises the device). */
+pmg_status pmg_dist_describe(pmg_dist d, int32_t lo_device, int32_t hi_device, pmg_dist_description *out)
+{
+  PMG_CHECK(d && out, PMG_ERR_ARG_NULL, "null argument");
+  memset(out, 0, sizeof *out);
+  int dev = -1;
+  PMG_HIP(hipGetDevice(&dev));
+  out->device = dev;
+  if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, dev) != hipSuccess) snprintf(out->pci_bus_id, sizeof out->pci_bus_id, "unknown");
+  const int32_t peer[2] = {lo_device, hi_device};
+  for (int s = 0; s < 2; ++s) {
+    int can = -1;
+    if (peer[s] >= 0) {
+      if (peer[s] == dev) can = 1; /* ranks sharing a device (rehearsal) */
+      else if (hipDeviceCanAccessPeer(&can, dev, peer[s]) != hipSuccess) can = -1;
+    }
+    out->peer_access[s] = can;
+  }
+  out->rank      = d->rank;
+  out->nranks    = d->nranks;
+  out->neighbour[0] = d->lo, out->neighbour[1] = d->hi;
+  snprintf(out->transport, sizeof out->transport, "%s", d->transport == 1 ? "ipc" : "rccl");
+  if (d->transport == 0 && d->comm && d->api.CommCount) {
+    int n = 0;
+    if (d->api.CommCount(d->comm, &n) == 0) out->rccl_comm_count = n;
+  }
+  if (d->spins_dev) {
+    unsigned long long v = 0;
+    PMG_HIP(hipDeviceSynchronize());
+    PMG_HIP(hipMemcpy(&v, d->spins_dev, sizeof v, hipMemcpyDeviceToHost));
+    out->halo_wait_polls = (uint64_t)v;
+  }
+  return PMG_SUCCESS;
 }
 
 pmg_status pmg_dist_get_info(pmg_dist d, int32_t *rank, int32_t *nranks, int64_t *capacity)

@@ -57,6 +57,9 @@ typedef struct {
   uint64_t      *slo, *shi;
   uint64_t       sval;
   unsigned      *counter, *err;
+  unsigned long long *spins; /* device word (may be null): polls of the flag words that found them not yet raised, summed over
+                                the face wavefronts of all launches -- 0 in steady state (the planes a colour needs were pushed
+                                a whole colour pass earlier); what a multi-GPU bench record reports as halo_wait_polls */
 } pmgk_grid_halo;
 /* sweeps the colour-`color` points of the kcount owned planes kbegin, kbegin+kstride, ...; halo may be NULL */
 int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, int kstride, const pmgk_grid_halo *halo, const double *b_cvec, double *y_cvec, void *stream);

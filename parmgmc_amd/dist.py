@@ -210,6 +210,17 @@ class RcclSlabDriver:
 
         check(lib.pmg_dist_check(self._h))
 
+    def describe(self, lo_device: int = -1, hi_device: int = -1) -> dict:
+        """pmg_dist_describe: device, PCI bus id, peer access to the z-neighbours' devices, transport, ncclCommCount, halo
+        wait polls -- this rank's entry of the multi-GPU bench record"""
+        import ctypes as C
+
+        from .capi import DistDescription, check, lib
+
+        d = DistDescription()
+        check(lib.pmg_dist_describe(self._h, lo_device, hi_device, C.byref(d)))
+        return d.as_dict()
+
     def disconnect(self):
         """local: unmap the peers' receive blocks"""
         from .capi import lib
@@ -378,6 +389,21 @@ class DistGridSampler:
         """after torch.cuda.synchronize(): raises if the halo transport lost a neighbour"""
         if self.rccl is not None:
             self.rccl.check()
+
+    def describe(self, lo_device: int = -1, hi_device: int = -1) -> dict:
+        """this rank's entry of a multi-GPU bench record (see RcclSlabDriver.describe); the torch P2P loop has no C object"""
+        if self.rccl is not None:
+            return self.rccl.describe(lo_device, hi_device)
+        import torch
+
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        pci = "unknown"
+        try:
+            p = torch.cuda.get_device_properties(dev)
+            pci = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        except Exception:  # noqa: BLE001
+            pass
+        return {"rank": self.rank, "nranks": self.world, "device": dev, "pci_bus_id": pci, "neighbour_ranks": [self.rank - 1 if self.rank > 0 else -1, self.rank + 1 if self.rank < self.world - 1 else -1], "peer_access_lo_hi": [-1, -1], "transport": self.transport, "rccl_comm_count": 0, "halo_wait_polls": 0}
 
     def destroy(self):
         """collective: orderly tear-down of the halo transport (call on every rank before building another one)"""

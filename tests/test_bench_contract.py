@@ -71,3 +71,44 @@ def test_bench_line_carries_the_contract_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "samples/s"
     assert d["finite"] is True and d["clock_settle"]["settle_launches"] > 0
+
+
+def test_multi_gpu_record_is_self_describing_by_construction():
+    """round 4: for N > 1 the line carries, per rank, the device index, its PCI bus id, peer access to the
+    z-neighbours' devices, the rank's own timed-region seconds and its halo-wait polls, plus ranks_seen (torch's world size,
+    ncclCommCount on the rccl transport) and min / median / max of the per-rank times.  Without a GPU: the C-ABI entry point
+    the record is read from exists with the struct layout the Python side assumes, and bench.py assembles every field."""
+    import ctypes as C
+
+    from parmgmc_amd import capi
+
+    assert "pmg_dist_describe" in capi.declared_symbols() and hasattr(capi.lib, "pmg_dist_describe")
+    assert C.sizeof(capi.DistDescription) == 8 * 4 + 8 + 32 + 8  # pmg_dist_description in include/parmgmc_hip.h
+    hdr = (ROOT / "include" / "parmgmc_hip.h").read_text()
+    assert "int32_t  rank, nranks, device, neighbour[2], peer_access[2], rccl_comm_count;" in hdr and "char     pci_bus_id[32], transport[8];" in hdr
+    keys = set(capi.DistDescription().as_dict())
+    assert {"rank", "device", "pci_bus_id", "peer_access_lo_hi", "neighbour_ranks", "transport", "rccl_comm_count", "halo_wait_polls"} <= keys
+    src = (ROOT / "bench.py").read_text()
+    for field in ('"ranks_seen"', '"torch_world_size"', '"rccl_comm_count"', '"timed_region_s"', '"min"', '"median"', '"max"', '"halo_wait_polls_total"', '"ranks"', '"local_rank"', "all_gather_object"):
+        assert field in src, field
+    cdrv = (ROOT / "examples" / "pmg_bench.c").read_text()
+    assert "pmg_dist_describe" in cdrv and "pci_bus_id" in cdrv and "halo_wait_polls" in cdrv
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharing_the_gpu_print_the_self_describing_record():
+    """the one-GPU rehearsal of `bench.py --gpus 2` (tools/bench_shared_gpu.sh): the N > 1 fields are there and sane"""
+    env = dict(os.environ, PMG_BENCH_SHARE_DEVICE="1", PMG_BENCH_SPAWN_TIMEOUT="500")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--grid-n", "64", "--steps", "6", "--warmup", "2", "--no-mgmc", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["halo_check"].startswith("bit-identical")
+    assert d["ranks_seen"]["torch_world_size"] == 2 and d["ranks_seen"]["records"] == 2 and d["ranks_seen"]["distinct_devices"] == 1  # shared device
+    assert d["timed_region_s"]["min"] <= d["timed_region_s"]["median"] <= d["timed_region_s"]["max"]
+    assert d["halo_wait_polls_total"] >= 0
+    rk = sorted(d["ranks"], key=lambda x: x["rank"])
+    assert [x["rank"] for x in rk] == [0, 1] and all(x["transport"] == "ipc" and x["device"] == 0 and len(x["pci_bus_id"]) >= 7 for x in rk)
+    assert rk[0]["neighbour_ranks"] == [-1, 1] and rk[1]["neighbour_ranks"] == [0, -1]
+    assert rk[0]["peer_access_lo_hi"] == [-1, 1] and rk[1]["peer_access_lo_hi"] == [1, -1]
