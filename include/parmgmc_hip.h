@@ -469,7 +469,9 @@ typedef struct pmg_rowblock_plan_s *pmg_rowblock_plan;
 pmg_status pmg_rowblock_plan_create(const pmg_host_comm *comm, const int64_t *row_starts, int64_t ncols, const int64_t *cols, int64_t nextra, const int64_t *extra, int32_t ncolors, const int32_t *colors_owned, pmg_rowblock_plan *plan);
 /* Is `colors_owned` a distance-1 colouring as far as this rank's rows can tell (no owned row shares its colour with one of
    its columns, owned or ghost -- the ghost rows' colours are the plan's)?  PMG_ERR_ARG_WRONG on EVERY rank if any rank finds a
-   conflict.  Every constructor that takes rows + a plan runs it (pmg_rowblock_sampler_create, pmg_rbh_build).  Collective. */
+   conflict.  Every constructor that takes rows + a plan runs it (pmg_rowblock_sampler_create, pmg_rbh_build).  First fit
+   yields such a colouring for STRUCTURALLY SYMMETRIC patterns (what PETSc assembles for these operators); a pattern in which r
+   lists c but c does not list r can defeat it and is refused here instead of being swept with a race.  Collective. */
 pmg_status pmg_rowblock_check_coloring(const pmg_host_comm *comm, pmg_rowblock_plan plan, const int64_t *rowptr, const int64_t *colidx_global, const int32_t *colors_owned);
 pmg_status pmg_rowblock_plan_get(pmg_rowblock_plan plan, int32_t *nghost, const int64_t **ghosts, const int64_t **send_ptr, const int32_t **send_rows, const int64_t **counts, const int64_t **recv_ptr, const int32_t **recv_src, const int32_t **recv_rows);
 void       pmg_rowblock_plan_destroy(pmg_rowblock_plan *plan);

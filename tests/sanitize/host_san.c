@@ -106,12 +106,13 @@ static void *san_rank(void *arg)
     int64_t       q  = 0;
     rp[0] = 0;
     for (int64_t r = r0; r < r1; ++r) {
-      const int64_t far = (r * 7 + 3) % n[l];
-      const int64_t cand[5] = {r - 1, r, r + 1, far, (n[l] - 1 - far)};
+      /* long-range couplings across the ranks, STRUCTURALLY SYMMETRIC (both are involutions: if r lists c, c lists r): a
+         multicolour sweep is race-free only if no row shares its colour with a column it reads, first fit guarantees that
+         for symmetric patterns, and pmg_rbh_build now checks it (pmg_rowblock_check_coloring) */
+      const int64_t cand[5] = {r - 1, r, r + 1, n[l] - 1 - r, n[l] % 2 == 0 ? (r + n[l] / 2) % n[l] : -1};
       for (int c = 0; c < 5; ++c) {
         int dup = cand[c] < 0 || cand[c] >= n[l];
         for (int d = 0; d < c && !dup; ++d) dup = cand[d] == cand[c];
-        /* structural symmetry is not needed by the plan builders; the colouring sees each row's own list */
         if (!dup) ci[q] = cand[c], v[q] = cand[c] == r ? 4.0 : -0.5, ++q;
       }
       rp[r - r0 + 1] = q;
