@@ -11,6 +11,14 @@
 #define PMG_RNG_TU lrc
 #include "pmg_rng.hpp"
 
+// rows per thread of the row-compact B^T y kernels: a block of 256 threads sums 256 * PMG_LRC_RPT support rows.  Round 3 used 16
+// (100 blocks for the 407 k support rows of the 257^3 level: 100 of 256 CUs, 16 dependent gathers per thread); 4 gives four
+// times the blocks and shorter chains: 257^3 k = 3 sample 0.823 -> 0.798 ms, k = 17 1.358 -> 1.287 ms (same box).  The
+// grouping of the partial sums changes the rounding of B^T y, not its order within a block.
+#ifndef PMG_LRC_RPT
+#define PMG_LRC_RPT 4
+#endif
+
 namespace {
 
 // partial[block*k + c] = sum over the block's rows of M[r + ld*c] * y[r]
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void lrc_gather_rows_kernel(int64_t ns, int k,
   for (int c = 0; c < k; ++c) Mc[q + ns * c] = M[r + ld * c];
 }
 
-// partial[block*k + c] = sum over the block's 4096 compact rows q of Mc[q + ns*c] * y[rows[q]].  A thread owns 16 rows
+// partial[block*k + c] = sum over the block's 256 * PMG_LRC_RPT compact rows q of Mc[q + ns*c] * y[rows[q]].  A thread owns PMG_LRC_RPT rows
 // (q0 + tid + 256 i): their positions and y values are fetched ONCE, all 32 loads in flight, and reused for every column;
 // per column the 16 factor loads are independent too.  (Round 1 walked the rows once per column with a load -> gather ->
 // fma chain per row: 100 us per call at 257^3 for k = 3, 0.4 of the 1.16 ms low-rank V-cycle sample.)  The order of
@@ -95,46 +103,46 @@ __global__ __launch_bounds__(256) void lrc_gather_rows_kernel(int64_t ns, int k,
 __global__ __launch_bounds__(256) void lrc_btx_rows_partial_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, const double *__restrict__ y, double *__restrict__ partial)
 {
   __shared__ double red[64][4];
-  const int64_t q0 = (int64_t)blockIdx.x * 4096 + threadIdx.x;
+  const int64_t q0 = (int64_t)blockIdx.x * (256 * PMG_LRC_RPT) + threadIdx.x;
   // three dependent fetches (positions -> y at the positions; the factors) from cold memory are what this kernel takes its
   // time for: the first column's factors are requested together with the positions, in front of the gathers that wait for
   // them, and every further column in front of the sum of the one before (round 4)
-  int64_t rr[16];
-  double  yv[16], m[16];
+  int64_t rr[PMG_LRC_RPT];
+  double  yv[PMG_LRC_RPT], m[PMG_LRC_RPT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < PMG_LRC_RPT; ++i) {
     const int64_t q = q0 + 256 * i;
     rr[i]           = q < ns ? rows[q] : -1;
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < PMG_LRC_RPT; ++i) {
     const int64_t q = q0 + 256 * i;
     m[i]            = q < ns ? Mc[q] : 0.0;
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) yv[i] = rr[i] >= 0 ? y[rr[i]] : 0.0;
+  for (int i = 0; i < PMG_LRC_RPT; ++i) yv[i] = rr[i] >= 0 ? y[rr[i]] : 0.0;
   for (int c0 = 0; c0 < k; c0 += 64) { // k <= 64 in practice: one round
     const int kc = min(64, k - c0);
     for (int c = 0; c < kc; ++c) {
-      double mn[16];
+      double mn[PMG_LRC_RPT];
       if (c0 + c + 1 < k) {
         const double *col = Mc + ns * (int64_t)(c0 + c + 1);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < PMG_LRC_RPT; ++i) {
           const int64_t q = q0 + 256 * i;
           mn[i]           = q < ns ? col[q] : 0.0;
         }
       }
       double s = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
+      for (int i = 0; i < PMG_LRC_RPT; ++i)
         if (q0 + 256 * i < ns) s = fma(m[i], yv[i], s);
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
       if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = s;
       if (c0 + c + 1 < k) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m[i] = mn[i];
+        for (int i = 0; i < PMG_LRC_RPT; ++i) m[i] = mn[i];
       }
     }
     __syncthreads();
@@ -176,22 +184,22 @@ __global__ void lrc_mul_kernel(int k, const double *__restrict__ a, const double
 // 9.5 + 2.5 for the two kernels -- on this chip the fence that publishes a block's sums to the other XCDs' L2s costs more than
 // the launch boundary it saves (gpurun_out/r4_lrc_trace.log; the V-cycle sample 0.900 ms fused against 0.879).
 
-// Block-wide sum of the k column sums of one block of 4096 compact rows, exactly as lrc_btx_rows_partial_kernel forms them:
-// a thread owns the rows q0 + 256 i, i < 16, in ascending order; wavefront shuffle tree; (red0 + red1) + (red2 + red3).
+// Block-wide sum of the k column sums of one block of 256 * PMG_LRC_RPT compact rows, exactly as lrc_btx_rows_partial_kernel forms them:
+// a thread owns the rows q0 + 256 i, i < PMG_LRC_RPT, in ascending order; wavefront shuffle tree; (red0 + red1) + (red2 + red3).
 // Thread c < kc holds the block's sum of column c0 + c on return (others: unspecified).  red: [64][4] doubles of LDS.
-__device__ __forceinline__ double lrc_block_colsum(int64_t ns, int kc, int64_t col0, const double *__restrict__ Mc, const double (&yv)[16], int64_t q0, double (*red)[4])
+__device__ __forceinline__ double lrc_block_colsum(int64_t ns, int kc, int64_t col0, const double *__restrict__ Mc, const double (&yv)[PMG_LRC_RPT], int64_t q0, double (*red)[4])
 {
   for (int c = 0; c < kc; ++c) {
     const double *col = Mc + ns * (col0 + c);
-    double        m[16];
+    double        m[PMG_LRC_RPT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < PMG_LRC_RPT; ++i) {
       const int64_t q = q0 + 256 * i;
       m[i]            = q < ns ? col[q] : 0.0;
     }
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < PMG_LRC_RPT; ++i)
       if (q0 + 256 * i < ns) s = fma(m[i], yv[i], s);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) void lrc_rhs_rows_kernel(int64_t ns, int k, co
   b[r]            = o + 1.0 * s;
 }
 
-// Small supports (one block of 4096 rows): B^T y AND the update that consumes it in ONE launch of one workgroup --
+// Small supports (one block of 256 * PMG_LRC_RPT rows): B^T y AND the update that consumes it in ONE launch of one workgroup --
 //   wk = scale o (M1^T y[rows1]);  v[rows2] += sign * M2 wk;  optionally w[rows2] = save[q]
 // (rows1 / M1 = the support of B on the level whose vector is read, rows2 / M2 = the block that is applied: Bb of the same
 // level for the post-correction, B of the next coarser level for the restricted residual term).  Same sums in the same
@@ -254,9 +262,9 @@ __global__ __launch_bounds__(256) void lrc_btx_axpy_small_kernel(int64_t ns1, in
   __shared__ double red[64][4];
   __shared__ double s_wk[64];
   const int64_t     q0 = threadIdx.x;
-  double            yv[16];
+  double            yv[PMG_LRC_RPT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < PMG_LRC_RPT; ++i) {
     const int64_t q = q0 + 256 * i;
     yv[i]           = q < ns1 ? y[rows1[q]] : 0.0;
   }
@@ -296,15 +304,17 @@ extern "C" int pmgk_lrc_rhs_rows(int64_t ns, int k, const double *Mc, const int6
   return launch_status();
 }
 
-/* one workgroup: ns1 <= 4096 (one block of lrc_btx_rows_partial_kernel), k <= 64; ns2 is looped over */
+/* one workgroup: ns1 <= pmgk_lrc_rows_per_block() (one block of lrc_btx_rows_partial_kernel), k <= 64; ns2 is looped over */
 extern "C" int pmgk_lrc_btx_axpy_small(int64_t ns1, int k, const double *M1, const int64_t *rows1, const double *y, const double *scale, double *wk, int64_t ns2, const double *M2, const int64_t *rows2, double sign, double *v, const double *save, double *w, void *stream)
 {
-  if (ns1 <= 0 || ns1 > 4096 || k <= 0 || k > 64) return 1;
+  if (ns1 <= 0 || ns1 > 256 * PMG_LRC_RPT || k <= 0 || k > 64) return 1;
   hipLaunchKernelGGL(lrc_btx_axpy_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ns1, k, M1, rows1, y, scale, wk, ns2, M2, rows2, sign, v, save, w);
   return launch_status();
 }
 
-extern "C" int pmgk_lrc_nblocks(int64_t n) { return (int)((n + 4095) / 4096); }
+extern "C" int pmgk_lrc_nblocks(int64_t n) { return (int)((n + 4095) / 4096); } /* dense form */
+extern "C" int pmgk_lrc_rows_per_block(void) { return 256 * PMG_LRC_RPT; }
+extern "C" int pmgk_lrc_rows_nblocks(int64_t ns) { return (int)((ns + 256 * PMG_LRC_RPT - 1) / (256 * PMG_LRC_RPT)); } /* row-compact form */
 
 extern "C" int pmgk_lrc_btx(int64_t n, int k, const double *M, int64_t ld, const double *y, double *partial, const double *scale, double *out, void *stream)
 {
@@ -352,7 +362,7 @@ extern "C" int pmgk_lrc_gather_rows(int64_t ns, int k, const double *M, int64_t 
 extern "C" int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *y, double *partial, const double *scale, double *out, void *stream)
 {
   if (ns <= 0 || k <= 0) return 0;
-  const int nb = pmgk_lrc_nblocks(ns);
+  const int nb = pmgk_lrc_rows_nblocks(ns);
   hipLaunchKernelGGL(lrc_btx_rows_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, y, partial);
   hipLaunchKernelGGL(lrc_reduce_kernel, dim3(k), dim3(64), 0, (hipStream_t)stream, nb, k, partial, scale, out);
   return launch_status();

@@ -138,6 +138,8 @@ int pmgk_q1_prolong_add(const pmgk_grid_layout *L, const pmgk_st27_dims *C, cons
 int pmgk_tri_gemv(int32_t n, int upper, const double *M, const double *x, const double *add, double *out, void *stream);
 /* low-rank (MATLRC) pieces: M is n x k column-major with leading dimension ld, k <= 64 */
 int pmgk_lrc_nblocks(int64_t n);
+int pmgk_lrc_rows_per_block(void);
+int pmgk_lrc_rows_nblocks(int64_t ns);
 int pmgk_lrc_btx(int64_t n, int k, const double *M, int64_t ld, const double *y, double *partial, const double *scale, double *out, void *stream);
 int pmgk_lrc_axpy_cols(int64_t n, int k, const double *M, int64_t ld, const double *coef, double sign, const double *in, double *out, void *stream);
 int pmgk_lrc_gemm_small(int64_t n, int k, const double *Cm, int64_t ld, const double *Sb, double *Bb, void *stream);

@@ -144,6 +144,11 @@ static pmg_status lrc_compact(pmg_lrc l)
   if (!st) st = pmg_dev_alloc((void **)&l->Bbc[0], cb);
   if (!st) st = pmg_dev_alloc((void **)&l->Bbc[1], cb);
   if (!st) st = pmg_dev_alloc((void **)&l->saved, sizeof(double) * (size_t)ns);
+  if (!st && pmgk_lrc_rows_nblocks(ns) > pmgk_lrc_nblocks(l->ld)) { /* the row-compact kernels cut the support into smaller blocks than the dense ones the rows */
+    pmg_dev_free(l->partial);
+    l->partial = NULL;
+    st         = pmg_dev_alloc((void **)&l->partial, sizeof(double) * (size_t)pmgk_lrc_rows_nblocks(ns) * (size_t)l->k);
+  }
   if (!st && (pmgk_lrc_gather_rows(ns, l->k, l->B, l->ld, l->rows, l->Bc, NULL) || pmgk_lrc_gather_rows(ns, l->k, l->Bb[0], l->ld, l->rows, l->Bbc[0], NULL) || pmgk_lrc_gather_rows(ns, l->k, l->Bb[1], l->ld, l->rows, l->Bbc[1], NULL))) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
   if (!st && hipDeviceSynchronize() != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device error while compacting the low-rank factors");
   if (st) return st;
@@ -251,7 +256,7 @@ static pmg_status lrc_flush_restore(pmg_lrc l, void *stream)
 
 /* one workgroup does B^T y and the update that consumes it (kernels_lrc.hip) when the support is one block of rows, the
    update's row set is small and nothing has to be summed over ranks in between */
-static int lrc_small(pmg_lrc l, int64_t ns2) { return l->ns > 0 && l->ns <= 4096 && ns2 <= 16384 && !l->reduce && !l->unfused; }
+static int lrc_small(pmg_lrc l, int64_t ns2) { return l->ns > 0 && l->ns <= pmgk_lrc_rows_per_block() && ns2 <= 16384 && !l->reduce && !l->unfused; }
 
 /* b_eff = b + B (sqrt(S) o eta), eta = row-stream normals of (seed + tag, counter); returns the device vector to
    sweep with.  Row-compact form: the noise term is added to the support rows of b IN PLACE (old values saved) and
