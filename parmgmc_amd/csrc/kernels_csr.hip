@@ -138,10 +138,30 @@ __global__ __launch_bounds__(256) void csr_spmv_rows_kernel(int32_t nrows, const
 {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
+  // entries in batches of SELL_BATCH like sell_row_sum: all value / column loads of a batch, then all gathers, then the sum in
+  // storage order (same terms, same order, same bits).  The plain loop ran load -> gather -> add per entry: two dependent
+  // fetches per ENTRY of a row of P^T (a dozen entries on an aggregation hierarchy), in a kernel that lives for 5 us
+  const int k0 = rowptr[r], k1 = rowptr[r + 1];
+  const int o  = rowpos[r];
+  double    yo = 0.0;
+  if (ACC) yo = y[o];
   double sum = 0.0;
-  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) sum = sum + vals[k] * x[colidx[k]];
-  const int o = rowpos[r];
-  y[o]        = ACC ? y[o] + sum : sum;
+  for (int kb = k0; kb < k1; kb += SELL_BATCH) {
+    double  a[SELL_BATCH], xv[SELL_BATCH];
+    int32_t cj[SELL_BATCH];
+#pragma unroll
+    for (int q = 0; q < SELL_BATCH; ++q) {
+      const int kk = min(kb + q, k1 - 1);
+      a[q]         = vals[kk];
+      cj[q]        = colidx[kk];
+    }
+#pragma unroll
+    for (int q = 0; q < SELL_BATCH; ++q) xv[q] = x[cj[q]];
+#pragma unroll
+    for (int q = 0; q < SELL_BATCH; ++q)
+      if (kb + q < k1) sum = sum + a[q] * xv[q];
+  }
+  y[o] = ACC ? yo + sum : sum;
 }
 
 __global__ void axpy_kernel(int64_t n, double alpha, const double *__restrict__ x, double *__restrict__ y)
