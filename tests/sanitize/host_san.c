@@ -59,13 +59,45 @@ STUB(pmg_distmcsor_create, pmg_mcsor m, pmg_dist d, int32_t nc, const int64_t *a
 STUB(pmg_distmcsor_destroy, pmg_distmcsor *h)
 STUB(pmg_dist_get_unique_id, const char *p, void *id)
 STUB(pmg_dist_create, pmg_grid g, int32_t r, int32_t n, const void *id, const char *p, int l, pmg_dist *d)
-STUB(pmg_dist_create_ipc, pmg_grid g, int32_t r, int32_t n, pmg_dist *d)
-STUB(pmg_dist_ipc_blob_bytes, int32_t *b)
-STUB(pmg_dist_ipc_export, pmg_dist d, void *b)
+/* the ipc transport's device layer: unsupported (as everywhere above) unless san_fail_on_rank >= 0 -- then the creation
+   SUCCEEDS on every rank but that one, which is the situation the tear-down of pmg_dist_create_comm must survive: some ranks
+   hold an object, one does not, and all of them have to pass the same collectives (advisor finding, round 3) */
+static int  san_fail_on_rank = -1;
+static char san_fake_dist[8];
+static int  san_disconnects[8], san_destroys[8];
+pmg_status pmg_dist_create_ipc(pmg_grid g, int32_t r, int32_t n, pmg_dist *d)
+{
+  (void)g; (void)n;
+  if (san_fail_on_rank < 0 || r == san_fail_on_rank) return PMG_ERR_SUP;
+  *d = (pmg_dist)&san_fake_dist[r];
+  return PMG_SUCCESS;
+}
+pmg_status pmg_dist_ipc_blob_bytes(int32_t *b)
+{
+  if (san_fail_on_rank < 0) return PMG_ERR_SUP;
+  *b = 16;
+  return PMG_SUCCESS;
+}
+pmg_status pmg_dist_ipc_export(pmg_dist d, void *b)
+{
+  if (san_fail_on_rank < 0) return PMG_ERR_SUP;
+  memset(b, (int)((char *)d - san_fake_dist) + 1, 16);
+  return PMG_SUCCESS;
+}
 STUB(pmg_dist_ipc_connect, pmg_dist d, const void *a, const void *b)
 STUB(pmg_dist_ipc_connect_all, pmg_dist d, const void *const *b)
-STUB(pmg_dist_ipc_disconnect, pmg_dist d)
-STUB(pmg_dist_destroy, pmg_dist *d)
+pmg_status pmg_dist_ipc_disconnect(pmg_dist d)
+{
+  if (san_fail_on_rank < 0) return PMG_ERR_SUP;
+  san_disconnects[(char *)d - san_fake_dist]++;
+  return PMG_SUCCESS;
+}
+pmg_status pmg_dist_destroy(pmg_dist *d)
+{
+  if (san_fail_on_rank < 0) return PMG_ERR_SUP;
+  if (d && *d) san_destroys[(char *)*d - san_fake_dist]++, *d = NULL;
+  return PMG_SUCCESS;
+}
 STUB(pmg_mgmc_create_hierarchy, int32_t l, pmg_mgmc *m)
 STUB(pmg_mgmc_set_level_operator, pmg_mgmc m, int32_t l, int32_t n, const int32_t *a, const int32_t *b, const double *c)
 STUB(pmg_mgmc_set_level_interpolation, pmg_mgmc m, int32_t l, int32_t n, int32_t k, const int32_t *a, const int32_t *b, const double *c)
@@ -146,6 +178,23 @@ static void *san_rank(void *arg)
   if (!fail && pmg_rbh_create_mgmc(h, (pmg_dist)&hc, &mg) != PMG_ERR_SUP) fail = 11; /* reaches the (stubbed) device layer and unwinds */
   pmg_rbh_destroy(&h);
   return (void *)fail;
+}
+
+/* pmg_dist_create_comm when the creation fails on ONE rank: an error on every rank, no rank left in a collective the
+   others skipped (the threads' all-gather is a pair of barriers: a mismatch hangs this program until the test's timeout) */
+static void *san_rank_create(void *arg)
+{
+  const int     rank = *(int *)arg;
+  int           rk   = rank;
+  pmg_host_comm hc   = {rank, SAN_RANKS, san_allgather, &rk};
+  pmg_dist      d    = (pmg_dist)&hc; /* must come back NULL */
+  const int     st   = pmg_dist_create_comm(&hc, "ipc", NULL, NULL, &d);
+  if (st == 0) return (void *)21;
+  if (d != NULL) return (void *)22;
+  /* the communicator is still usable: everybody passes one more all-gather */
+  int32_t z = rank, all[SAN_RANKS];
+  if (hc.allgather(hc.ctx, &z, sizeof z, all) || all[0] != 0 || all[SAN_RANKS - 1] != SAN_RANKS - 1) return (void *)23;
+  return NULL;
 }
 
 #define REQUIRE(c) \
@@ -266,6 +315,16 @@ int main(void)
       if (ret) fprintf(stderr, "host_san: row-block rank %d failed at step %ld: %s\n", r, (long)(intptr_t)ret, pmg_last_error_string());
       REQUIRE(ret == NULL);
     }
+    san_fail_on_rank = 1;
+    for (int r = 0; r < SAN_RANKS; ++r) REQUIRE(pthread_create(&th[r], NULL, san_rank_create, &ids[r]) == 0);
+    for (int r = 0; r < SAN_RANKS; ++r) {
+      void *ret = NULL;
+      REQUIRE(pthread_join(th[r], &ret) == 0);
+      if (ret) fprintf(stderr, "host_san: transport-creation rank %d failed at step %ld\n", r, (long)(intptr_t)ret);
+      REQUIRE(ret == NULL);
+    }
+    REQUIRE(san_disconnects[0] == 1 && san_destroys[0] == 1 && san_disconnects[2] == 1 && san_destroys[2] == 1 && san_destroys[1] == 0);
+    san_fail_on_rank = -1;
     /* MatMPIAIJGetSeqAIJ's blocks -> rows, both orders, 32-bit indices */
     const int32_t ad_rp[3] = {0, 2, 4}, ad_ci[4] = {0, 1, 0, 1}, ao_rp[3] = {0, 1, 3}, ao_ci[3] = {1, 0, 2}, ga[3] = {0, 1, 6};
     const double  ad_v[4] = {4, -1, -1, 4}, ao_v[3] = {-2, -3, -5};
