@@ -68,9 +68,9 @@ __device__ __forceinline__ double from_next(double v)
 // tile are the L2-resident neighbours of the next, and the shares differ by at most one tile (bands of line tiles of a
 // 2^k+1 grid cannot be balanced: 33 tiles over 8 XCDs leave one XCD with 5 and the others with 4).
 // Placement only: no result depends on it.  Returns false for the padding blocks.
-__device__ __forceinline__ bool xcd_block(int nbx, int nby, int nbz, int &bx, int &by, int &bz)
+__device__ __forceinline__ bool xcd_block(int nbx, int nby, int nbz, int &bx, int &by, int &bz, int bid = (int)blockIdx.x)
 {
-  const int     bid = (int)blockIdx.x, xcd = bid & 7, q = bid >> 3; // q: index inside this XCD's share
+  const int     xcd = bid & 7, q = bid >> 3; // q: index inside this XCD's share
   const int64_t T   = (int64_t)nby * nbz;
   const int     lo = (int)(xcd * T / 8), hi = (int)((xcd + 1) * T / 8);
   bx               = q % nbx;
@@ -97,6 +97,41 @@ struct pair_ctx {
   double   om1;
   const double *gcoef;
 };
+
+// How the pairs of a line are dealt to wavefronts (round 4).  A wavefront holds `valid` pairs of one line plus `halo` lanes
+// on either side that only supply their neighbours; a line of 2^k+1 points has 2^(k-1)+1 pairs -- ONE more than a power of
+// two -- so its last x segment is almost empty (129 pairs = 60 + 60 + 9, 65 = 60 + 5) and cost a whole wavefront per line:
+// a third of the 257^3 level's wavefronts, half of the 129^3 level's (tools/st27bench.py with that segment dropped:
+// residual 174 -> 129 us, noisy sweep 233 -> 178 us at 257^3; 24 -> 15 and 49 -> 32 us at 129^3).  The REMAINDER segment
+// is therefore swept by a second launch whose wavefronts hold the remainders of `nseg` different lines side by side, each
+// with its own halo lanes (segment width segw = rem + 2 halo); everything that was wave-uniform per line is per lane
+// there.  Same arithmetic per point: same bits.
+struct pair_split {
+  int nbx_main; // x segments of the one-line-per-wavefront launch
+  int p0;       // first pair of the remainder segment (packed launch), -1: none
+  int segw, nseg;
+};
+static inline pair_split split_pairs(int npairs, int valid, int halo)
+{
+  pair_split P;
+  const int  nbx = (npairs + valid - 1) / valid, rem = npairs - valid * (nbx - 1), segw = rem + 2 * halo;
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("PMG_ST27_PACK_REMAINDER");
+    env           = e ? atoi(e) : 1;
+  }
+  if (env && 64 / segw >= 2) { // two or more remainders fit one wavefront
+    P.nbx_main = nbx - 1;
+    P.p0       = valid * (nbx - 1);
+    P.segw     = segw;
+    P.nseg     = 64 / segw;
+  } else {
+    P.nbx_main = nbx;
+    P.p0       = -1;
+    P.segw = P.nseg = 0;
+  }
+  return P;
+}
 
 // New values of the two points of a pair.  FIRST1: the point x1 is swept before x0 (backward order).
 // get_row(row, r) delivers row `row` = 3 (dz+1) + (dy+1) of the neighbourhood as r = y at x0-1, x0, x1, x1+1, holding the
@@ -200,12 +235,14 @@ __device__ __forceinline__ void load_row(double (&r)[4], const double *vec, int 
 #endif
 // ZIN: y_in is all zeros and is not read (the pre-smoothing sweep of a V-cycle level starts from a zero guess: no memset of
 // the level's iterate, no loads of zeros); ZOTHER: the planes of the other z-parity are zero too (first phase of such a sweep)
-template <bool NOISY, bool BACKWARD, bool ZIN, bool ZOTHER>
-__global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(PMG_ST27_PAIR_WAVES, 8))) void st27_pair_phase_kernel(pmgk_st27 S, int nbx, int nby, int nbz, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ b, const double *y_in, double *y_out, const double *y_other)
+// PACK: the remainder x segment (see split_pairs below): the wavefront w of a workgroup sweeps its line of `nseg` different
+// line tiles side by side -- lane = segment * segw + slot, pair p0 - HL + slot, line tile nseg * by + segment -- so that what
+// depends on the line is per lane; the lanes of a segment whose line tile lies beyond the plane work on a valid line and
+// store nothing (no divergent exit: neighbouring lanes exchange values by DPP).  Line tiles are 2 PT = 8 lines apart: the
+// parity of a line, which decides how the Box-Muller pairs are shared, is the same in all segments of a wavefront.
+template <bool NOISY, bool BACKWARD, bool ZIN, bool ZOTHER, bool PACK>
+__device__ __forceinline__ void st27_pair_phase_body(const pmgk_st27 &S, int bid, int nbx, int nby, int nbz, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, int p0, int segw, int nseg, const double *__restrict__ b, const double *y_in, double *y_out, const double *y_other, double *s_coef, double *s_idiag, double *s_sqrtd, pmg::LogTabEntry *s_logtab, d2 (*s_new)[64])
 {
-  __shared__ double           s_coef[27 * 27], s_idiag[27], s_sqrtd[27];
-  __shared__ pmg::LogTabEntry s_logtab[NOISY ? PMG_LOGTAB_SIZE : 1];
-  __shared__ d2               s_new[PT + 1][64];
   const int                   lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int                   tid  = lane + 64 * w;
   for (int q = tid; q < 27 * 27; q += 64 * (PT + 1)) s_coef[q] = S.coef[q]; // (padding blocks of the last band leave below, before the barrier)
@@ -214,13 +251,24 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
     s_sqrtd[tid] = S.sqrtdiag[tid];
   }
   int bx, by, bz;
-  if (!xcd_block(nbx, nby, nbz, bx, by, bz)) return; // whole workgroup: before any barrier
+  if (!xcd_block(nbx, nby, nbz, bx, by, bz, bid)) return; // whole workgroup: before any barrier
   if (NOISY) pmg::load_log_table(s_logtab);
   __syncthreads();
 
   const int nx = S.nx, ny = S.ny;
   const int npairs = (nx + 1) / 2;
-  const int p      = VALID * bx - HL + lane;
+  int  p, byl = by;
+  bool seg_ok = true, final_lane;
+  if (PACK) {
+    const int sidx = lane / segw, slot = lane - sidx * segw;
+    p          = p0 - HL + slot;
+    byl        = by * nseg + sidx;
+    seg_ok     = sidx < nseg;
+    final_lane = seg_ok && slot >= HL && slot < segw - HL;
+  } else {
+    p          = VALID * bx - HL + lane;
+    final_lane = lane >= HL && lane < HL + VALID; // lanes whose results are complete at the end of each stage
+  }
   const int pc     = min(max(p, 0), npairs - 1); // inactive lanes work on a valid pair and publish zeros
   pair_ctx  C;
   C.nx   = nx;
@@ -229,26 +277,34 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
   C.x0   = 2 * pc;
   C.xu   = 2 * p;
   C.k    = kfirst + 2 * bz;
-  C.act0 = p >= 0 && p < npairs;
-  C.act1 = C.act0 && C.x0 + 1 < nx;
+  const bool pact0 = p >= 0 && p < npairs && seg_ok, pact1 = pact0 && C.x0 + 1 < nx;
+  C.act0 = pact0;
+  C.act1 = pact1;
   C.key0 = key0;
   C.key1 = key1;
   C.sweep = sweep;
   C.om1   = one_minus_omega;
   C.gcoef = S.coef;
   const int  xc0 = C.x0;
-  const bool final_lane = lane >= HL && lane < HL + VALID; // lanes whose results are complete at the end of each stage
-  const int  jt = 2 * PT * by;
+  const int  jt = 2 * PT * byl;
   const bool hasD = C.k > 0, hasU = C.k < S.nzg - 1;
   const int  kl = C.k - S.kz0; // plane inside the slab: addresses; C.k (global) keys the noise and the boundary classes
 
   // ---- stage A: the lines of the y-parity that is swept first --------------------------------------------------------
   {
-    const int jA = BACKWARD ? jt - 1 + 2 * w : jt + 2 * w;
-    d2        nw = {0.0, 0.0};
-    if (jA >= 0 && jA < ny) {
+    const int  jAu = BACKWARD ? jt - 1 + 2 * w : jt + 2 * w;
+    const bool okA = jAu >= 0 && jAu < ny;
+    const int  jA  = PACK ? min(max(jAu, 0), ny - 1) : jAu;
+    d2         nw  = {0.0, 0.0};
+    if (PACK) { // per lane: a lane without a line sweeps a valid one as an inactive lane (zeros, no store)
+      C.act0 = pact0 && okA;
+      C.act1 = pact1 && okA;
+    }
+    if (PACK || okA) {
       C.j    = jA;
-      C.line = (int64_t)nx * (jA + (int64_t)ny * C.k);
+      // PACK: from the UNCLAMPED line -- its parity (the wave-uniform branch of the noise in sweep_pair) is that of the valid
+      // segments' lines, which a clamped line's need not be (backward, first tile: line -1 clamps to line 0)
+      C.line = (int64_t)nx * ((PACK ? jAu : jA) + (int64_t)ny * C.k);
       const int jS = jA > 0 ? jA - 1 : jA, jN = jA < ny - 1 ? jA + 1 : jA;
       const int64_t lrow = (int64_t)nx * (jA + (int64_t)ny * (kl + 1)) + xc0;
       const d2u     bv   = *reinterpret_cast<const d2u *>(b + lrow);
@@ -273,8 +329,8 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
   // BEFORE the barrier: their latency runs under the wait for stage A's slowest wavefront (257^3 phase 135 -> 131 us)
   d2u pre[9];
   {
-    const int jB = BACKWARD ? jt + 2 * w : jt + 2 * w + 1;
-    if (w < PT && jB < ny) {
+    const int jBu = BACKWARD ? jt + 2 * w : jt + 2 * w + 1, jB = PACK ? min(jBu, ny - 1) : jBu;
+    if (w < PT && (PACK || jB < ny)) {
       const int jS = jB > 0 ? jB - 1 : jB, jN = jB < ny - 1 ? jB + 1 : jB;
 #pragma unroll
       for (int row = 0; row < 9; ++row) {
@@ -292,10 +348,14 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
   __syncthreads();
   // ---- stage B: the lines in between, whose in-plane neighbours above and below are the new values in LDS ------------
   if (w < PT) {
-    const int jB = BACKWARD ? jt + 2 * w : jt + 2 * w + 1;
-    if (jB < ny) {
+    const int jBu = BACKWARD ? jt + 2 * w : jt + 2 * w + 1, jB = PACK ? min(jBu, ny - 1) : jBu;
+    if (PACK) {
+      C.act0 = pact0 && jBu < ny;
+      C.act1 = pact1 && jBu < ny;
+    }
+    if (PACK || jB < ny) {
       C.j    = jB;
-      C.line = (int64_t)nx * (jB + (int64_t)ny * C.k);
+      C.line = (int64_t)nx * ((PACK ? jBu : jB) + (int64_t)ny * C.k);
       const int64_t lrow = (int64_t)nx * (jB + (int64_t)ny * (kl + 1)) + xc0;
       const d2u     bv   = *reinterpret_cast<const d2u *>(b + lrow);
       const d2      bb   = {bv.x, bv.y};
@@ -327,8 +387,22 @@ __global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(P
   }
 }
 
-// r = b - A y with the pair mapping (dense loads); the diagonal term is added last, like st27_residual_kernel
-__global__ __launch_bounds__(256) void st27_pair_residual_kernel(pmgk_st27 S, int nbx, int nby, int nbz, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
+// The full x segments (PACK = false) and the packed remainder segments (PACK = true) are two launches: as ONE kernel with a
+// workgroup-uniform branch between the two bodies the register allocation no longer fits 72 VGPRs (84, the noise-free
+// instantiations 96 with spills) and costs a wavefront per SIMD everywhere.
+template <bool NOISY, bool BACKWARD, bool ZIN, bool ZOTHER, bool PACK>
+__global__ __launch_bounds__(64 * (PT + 1)) __attribute__((amdgpu_waves_per_eu(PMG_ST27_PAIR_WAVES, 8))) void st27_pair_phase_kernel(pmgk_st27 S, int nbx, int nby, int nbz, int kfirst, double one_minus_omega, uint32_t key0, uint32_t key1, uint64_t sweep, int p0, int segw, int nseg, const double *__restrict__ b, const double *y_in, double *y_out, const double *y_other)
+{
+  __shared__ double           s_coef[27 * 27], s_idiag[27], s_sqrtd[27];
+  __shared__ pmg::LogTabEntry s_logtab[NOISY ? PMG_LOGTAB_SIZE : 1];
+  __shared__ d2               s_new[PT + 1][64];
+  st27_pair_phase_body<NOISY, BACKWARD, ZIN, ZOTHER, PACK>(S, (int)blockIdx.x, nbx, nby, nbz, kfirst, one_minus_omega, key0, key1, sweep, p0, segw, nseg, b, y_in, y_out, y_other, s_coef, s_idiag, s_sqrtd, s_logtab, s_new);
+}
+
+// r = b - A y with the pair mapping (dense loads); the diagonal term is added last, like st27_residual_kernel.
+// PACK: the remainder segments of nseg lines per wavefront (pair p0 + slot - 1 of line (4 by + wy) nseg + lane / segw)
+template <bool PACK>
+__global__ __launch_bounds__(256) void st27_pair_residual_kernel(pmgk_st27 S, int nbx, int nby, int nbz, int p0, int segw, int nseg, const double *__restrict__ b, const double *__restrict__ y, double *__restrict__ r)
 {
   __shared__ double s_coef[27 * 27];
   const int         tid = threadIdx.x + 64 * threadIdx.y;
@@ -337,12 +411,26 @@ __global__ __launch_bounds__(256) void st27_pair_residual_kernel(pmgk_st27 S, in
   for (int q = tid; q < 27 * 27; q += 256) s_coef[q] = S.coef[q];
   __syncthreads();
   const int nx = S.nx, ny = S.ny;
-  // lanes 0 and 63 only supply their neighbours with the values beside the pairs: 62 pairs per wavefront
+  // lanes 0 and 63 (PACK: the first and last lane of a segment) only supply their neighbours with the values beside the
+  // pairs: 62 pairs per wavefront
   const int npairs = (nx + 1) / 2;
-  const int p = 62 * bx - 1 + (int)threadIdx.x, j = 4 * by + __builtin_amdgcn_readfirstlane(threadIdx.y), k = S.kz0 + bz; // global plane
-  if (j >= ny) return; // wave-uniform
+  const int lane = (int)threadIdx.x, wy = __builtin_amdgcn_readfirstlane(threadIdx.y), k = S.kz0 + bz; // global plane
+  int       p, j;
+  bool      inner;
+  if (PACK) {
+    const int sidx = lane / segw, slot = lane - sidx * segw;
+    p     = p0 - 1 + slot;
+    j     = (4 * by + wy) * nseg + sidx;
+    inner = sidx < nseg && slot >= 1 && slot <= segw - 2 && j < ny;
+    j     = min(j, ny - 1); // a lane without a line works on a valid one and stores nothing (its neighbours use DPP)
+  } else {
+    p     = 62 * bx - 1 + lane;
+    j     = 4 * by + wy;
+    inner = lane >= 1 && lane <= 62;
+    if (j >= ny) return; // wave-uniform
+  }
   const int  x0   = 2 * min(max(p, 0), npairs - 1);
-  const bool act0 = p >= 0 && p < npairs && threadIdx.x >= 1 && threadIdx.x <= 62, act1 = act0 && x0 + 1 < nx;
+  const bool act0 = p >= 0 && p < npairs && inner, act1 = act0 && x0 + 1 < nx;
   const int  jS = j > 0 ? j - 1 : j, jN = j < ny - 1 ? j + 1 : j, kD = k > 0 ? k - 1 : k, kU = k < S.nzg - 1 ? k + 1 : k;
   const int     cyz  = 3 * pos_class(j, ny) + 9 * pos_class(k, S.nzg);
   const double *cf0 = s_coef + 27 * (pos_class(x0, nx) + cyz), *cf1 = s_coef + 27 * (pos_class(x0 + 1, nx) + cyz);
@@ -380,10 +468,17 @@ void launch_phase(const pmgk_st27 &S, int pz, double om1, uint64_t seed, uint64_
 {
   const int kfirst = S.kz0 + ((pz - S.kz0) & 1), cz = (S.kz0 + S.nz - kfirst + 1) / 2; // this slab's planes of the (global) parity pz
   if (cz <= 0) return;
-  const int  npairs = (S.nx + 1) / 2;
-  const int  nbx = (npairs + VALID - 1) / VALID, nby = (S.ny + 2 * PT - 1) / (2 * PT);
-  const dim3 grid(xcd_grid(nbx, nby, cz)), block(64, PT + 1);
-  hipLaunchKernelGGL((st27_pair_phase_kernel<NOISY, BACKWARD, ZIN, ZOTHER>), grid, block, 0, s, S, nbx, nby, cz, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, b, y_in, y_out, y_other);
+  const int        npairs = (S.nx + 1) / 2;
+  const pair_split P      = split_pairs(npairs, VALID, HL);
+  const int        nby    = (S.ny + 2 * PT - 1) / (2 * PT);
+  const dim3       block(64, PT + 1);
+  // the two launches of a phase are independent of each other (disjoint pairs of the same lines; what one reads of the
+  // other's pairs are OLD values from y_in / y_other, or first-colour values it recomputes in its halo lanes)
+  if (P.nbx_main > 0) hipLaunchKernelGGL((st27_pair_phase_kernel<NOISY, BACKWARD, ZIN, ZOTHER, false>), dim3(xcd_grid(P.nbx_main, nby, cz)), block, 0, s, S, P.nbx_main, nby, cz, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, 0, 0, 0, b, y_in, y_out, y_other);
+  if (P.p0 >= 0) {
+    const int nbyp = (nby + P.nseg - 1) / P.nseg;
+    hipLaunchKernelGGL((st27_pair_phase_kernel<NOISY, BACKWARD, ZIN, ZOTHER, true>), dim3(xcd_grid(1, nbyp, cz)), block, 0, s, S, 1, nbyp, cz, kfirst, om1, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, P.p0, P.segw, P.nseg, b, y_in, y_out, y_other);
+  }
 }
 
 } // namespace
@@ -429,9 +524,13 @@ extern "C" int pmgk_st27_sweep_pp(const pmgk_st27 *S, int backward, double omega
 extern "C" int pmgk_st27_residual_pair(const pmgk_st27 *S, const double *b, const double *y, double *r, void *stream)
 {
   if (S->nz <= 0) return 0; /* z-slabs too: the slab's planes, neighbours in the ghost planes */
-  const int  npairs = (S->nx + 1) / 2;
-  const int  nbx = (npairs + 61) / 62, nby = (S->ny + 3) / 4;
-  const dim3 grid(xcd_grid(nbx, nby, S->nz)), block(64, 4);
-  hipLaunchKernelGGL(st27_pair_residual_kernel, grid, block, 0, (hipStream_t)stream, *S, nbx, nby, S->nz, b, y, r);
+  const int        npairs = (S->nx + 1) / 2;
+  const pair_split P      = split_pairs(npairs, 62, 1);
+  const int        nby    = (S->ny + 3) / 4;
+  if (P.nbx_main > 0) hipLaunchKernelGGL((st27_pair_residual_kernel<false>), dim3(xcd_grid(P.nbx_main, nby, S->nz)), dim3(64, 4), 0, (hipStream_t)stream, *S, P.nbx_main, nby, S->nz, 0, 0, 0, b, y, r);
+  if (P.p0 >= 0) { /* the remainder segments, nseg lines per wavefront */
+    const int nbyp = (S->ny + 4 * P.nseg - 1) / (4 * P.nseg);
+    hipLaunchKernelGGL((st27_pair_residual_kernel<true>), dim3(xcd_grid(1, nbyp, S->nz)), dim3(64, 4), 0, (hipStream_t)stream, *S, 1, nbyp, S->nz, P.p0, P.segw, P.nseg, b, y, r);
+  }
   return launch_status();
 }
