@@ -1695,7 +1695,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
     if (l < top || !top_has_guess) {
       /* class-stencil levels with the out-of-place sweep: no memset, the first sweep is told that its input is zero */
-      if (Lv->x2 && st27_use_pair(Lv) && !Lv->lrc && h->nu >= 1) Lv->x_unset = 1;
+      if (Lv->x2 && st27_use_pair(Lv) && h->nu >= 1) Lv->x_unset = 1; /* (also under a low-rank update: the noise term changes b, the repair acts on the swept iterate -- round 3 excluded those levels without need and paid three zero fills and twelve full phase launches per 257^3 sample) */
       else PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
     }
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
@@ -1793,7 +1793,7 @@ pmg_status pmg_mgmc_get_algorithmic_bytes(pmg_mgmc h, double *total, double *per
       const mg_level *Cc = &h->lv[l - 1];
       const double    Nc = Cc->is_grid || Cc->padded ? (double)Cc->nx * Cc->ny * Cc->nzl : (double)(Cc->rb ? Cc->rb_nowned : Cc->n);
       const int has_guess = l == top && !h->correction_form;
-      const int unset     = !has_guess && Lv->x2 && st27_use_pair(Lv) && !Lv->lrc && h->nu >= 1; /* zero-guess out-of-place sweep */
+      const int unset     = !has_guess && Lv->x2 && st27_use_pair(Lv) && h->nu >= 1; /* zero-guess out-of-place sweep */
       by += 2.0 * nsw * (sweep + lrsw);
       if (!has_guess) by += unset ? -8.0 * N : 8.0 * N; /* the first sweep does not read x / the zero fill */
       const int fused = Lv->is_grid && Lv->grid_transfer && !Lv->cpos_dev && !h->no_fused &&
