@@ -170,15 +170,27 @@ __global__ void axpy_kernel(int64_t n, double alpha, const double *__restrict__ 
   if (i < n) y[i] = y[i] + alpha * x[i];
 }
 
-__global__ void fill_normal_rows_kernel(int64_t n, uint32_t key0, uint32_t key1, uint64_t sweep, double *__restrict__ xi)
+/* SCALED: xi = scale o z in the same launch (VecSetRandomStandardNormal + VecPointwiseMult of the low-rank noise terms,
+   src/pc_mcgibbs.c:130-134): the product a separate kernel would form, one dependent launch fewer */
+template <bool SCALED>
+__global__ void fill_normal_rows_kernel(int64_t n, uint32_t key0, uint32_t key1, uint64_t sweep, const double *__restrict__ scale, double *__restrict__ xi)
 {
   __shared__ pmg::LogTabEntry s_logtab[PMG_LOGTAB_SIZE];
   pmg::load_log_table(s_logtab);
   __syncthreads();
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (2 * q >= n) return;
+  double s0 = 1., s1 = 1.;
+  if (SCALED) {
+    s0 = scale[2 * q];
+    if (2 * q + 1 < n) s1 = scale[2 * q + 1];
+  }
   double z0, z1;
   pmg::normal_pair((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)sweep, (uint32_t)(sweep >> 32), key0, key1, s_logtab, z0, z1);
+  if (SCALED) {
+    z0 *= s0;
+    z1 *= s1;
+  }
   xi[2 * q] = z0;
   if (2 * q + 1 < n) xi[2 * q + 1] = z1;
 }
@@ -245,6 +257,14 @@ extern "C" int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, d
 {
   if (n <= 0) return 0;
   const int64_t pairs = (n + 1) / 2;
-  hipLaunchKernelGGL(fill_normal_rows_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, xi);
+  hipLaunchKernelGGL((fill_normal_rows_kernel<false>), dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, (const double *)nullptr, xi);
+  return launch_status();
+}
+
+extern "C" int pmgk_fill_normal_rows_scaled(int64_t n, uint64_t seed, uint64_t sweep, const double *scale, double *xi, void *stream)
+{
+  if (n <= 0) return 0;
+  const int64_t pairs = (n + 1) / 2;
+  hipLaunchKernelGGL((fill_normal_rows_kernel<true>), dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, scale, xi);
   return launch_status();
 }

@@ -604,6 +604,17 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
     // the lines beside the thread's three are fetched a plane ahead like its own: in the step in which their owners load
     // them, so that one of the two requests finds the line in the L2
     const int      jS = min(max(2 * J - 2, 0), jmax), jN = min(max(2 * J + 2, 0), jmax);
+#ifdef PMG_RR_PROBE_IDEAL /* timing only: every wavefront fetches the two fine lines it would OWN in a tiled form, nothing else */
+    (void)jS;
+    (void)jN;
+#pragma unroll
+    for (int i = 1; i < 3; ++i) {
+      const int      jc = min(max(2 * J - 1 + i, 0), jmax);
+      Uv[i] = rr_load_line(pu, (uint32_t)jc * sx8 + T.lo, (jc + ku) & 1);
+    }
+    Uv[0] = Uv[2];
+    const rr_line hSu = Uv[1], hNu = Uv[1];
+#else
     const rr_line  hSu = rr_load_line(pu, (uint32_t)jS * sx8 + T.lo, (jS + ku) & 1);
     const rr_line  hNu = rr_load_line(pu, (uint32_t)jN * sx8 + T.lo, (jN + ku) & 1);
 #pragma unroll
@@ -611,10 +622,16 @@ __global__ __launch_bounds__(256) void grid_residual_restrict_kernel(pmgk_grid_l
       const int      jc = min(max(2 * J - 1 + i, 0), jmax);
       Uv[i] = rr_load_line(pu, (uint32_t)jc * sx8 + T.lo, (jc + ku) & 1);
     }
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int      j = 2 * J - 1 + i, jc = min(max(j, 0), jmax);
+#ifdef PMG_RR_PROBE_IDEAL
+      const int      jb = min(max(2 * J - 1 + (i == 0 ? 2 : i), 0), jmax);
+      const rr_line  bb = rr_load_line(pb, (uint32_t)jb * sx8 + T.lo, (jb + k) & 1);
+#else
       const rr_line  bb = rr_load_line(pb, (uint32_t)jc * sx8 + T.lo, (jc + k) & 1);
+#endif
       const rr_line &S = i == 0 ? hS : Cv[i > 0 ? i - 1 : 0], &N = i == 2 ? hN : Cv[i < 2 ? i + 1 : 2];
       const bool     hasS = jc > 0, hasN = jc < jmax, inner = hasS && hasN;
       residual_consts Kc;

@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void lrc_gather_rows_kernel(int64_t ns, int k,
 // per column the 16 factor loads are independent too.  (Round 1 walked the rows once per column with a load -> gather ->
 // fma chain per row: 100 us per call at 257^3 for k = 3, 0.4 of the 1.16 ms low-rank V-cycle sample.)  The order of
 // every sum is unchanged (rows ascending per thread, the same wave and block reductions): same bits.
-__global__ __launch_bounds__(256) void lrc_btx_rows_partial_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, const double *__restrict__ y, double *__restrict__ partial)
+// RESTORE: w[rows[q]] = save[q] in the same pass (lrc_scatter_rows_kernel: the right-hand side entries under the noise term go
+// back behind the sweep) -- a load and a store per row beside the sums, on nobody's dependency chain.
+template <bool RESTORE>
+__global__ __launch_bounds__(256) void lrc_btx_rows_partial_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, const double *__restrict__ y, double *__restrict__ partial, const double *__restrict__ save, double *__restrict__ w)
 {
   __shared__ double red[64][4];
   const int64_t q0 = (int64_t)blockIdx.x * (256 * PMG_LRC_RPT) + threadIdx.x;
@@ -119,8 +122,21 @@ __global__ __launch_bounds__(256) void lrc_btx_rows_partial_kernel(int64_t ns, i
     const int64_t q = q0 + 256 * i;
     m[i]            = q < ns ? Mc[q] : 0.0;
   }
+  double sv[PMG_LRC_RPT];
+  if (RESTORE) {
+#pragma unroll
+    for (int i = 0; i < PMG_LRC_RPT; ++i) {
+      const int64_t q = q0 + 256 * i;
+      sv[i]           = q < ns ? save[q] : 0.0;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < PMG_LRC_RPT; ++i) yv[i] = rr[i] >= 0 ? y[rr[i]] : 0.0;
+  if (RESTORE) {
+#pragma unroll
+    for (int i = 0; i < PMG_LRC_RPT; ++i)
+      if (rr[i] >= 0) w[rr[i]] = sv[i];
+  }
   for (int c0 = 0; c0 < k; c0 += 64) { // k <= 64 in practice: one round
     const int kc = min(64, k - c0);
     for (int c = 0; c < kc; ++c) {
@@ -160,6 +176,34 @@ __global__ __launch_bounds__(256) void lrc_axpy_rows_kernel(int64_t ns, int k, c
   for (int c = 0; c < k; ++c) s = fma(Mc[q + ns * c], coef[c], s);
   const int64_t r = rows[q];
   const double  o = v[r];
+  if (save) save[q] = o;
+  v[r] = o + sign * s;
+}
+
+// lrc_reduce_kernel + lrc_axpy_rows_kernel in one launch: EVERY block adds the nb partial sums of the k columns itself, in
+// lrc_reduce_kernel's order (one wavefront per column: lane l adds the blocks l, l + 64, ..., then the shuffle tree; scale
+// applied to the sum) -- the same bits -- while its own row positions, old values and first factors are already on their way.
+// The partial sums are a few KB in L2; the launch this removes is one of three dependent ones per repair.  k <= 64.
+__global__ __launch_bounds__(256) void lrc_reduce_axpy_rows_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, int nb, const double *__restrict__ partial, const double *__restrict__ scale, double sign, double *__restrict__ v, double *__restrict__ save)
+{
+  __shared__ double s_coef[64];
+  const int64_t     q    = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool        live = q < ns;
+  const int64_t     r    = live ? rows[q] : 0;
+  const double      m0   = live ? Mc[q] : 0.0;
+  const int         wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = wv; c < k; c += 4) {
+    double s = 0.0;
+    for (int b = lane; b < nb; b += 64) s += partial[(int64_t)b * k + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) s_coef[c] = scale ? scale[c] * s : s;
+  }
+  const double o = live ? v[r] : 0.0;
+  __syncthreads();
+  if (!live) return;
+  double s = fma(m0, s_coef[0], 0.0);
+  for (int c = 1; c < k; ++c) s = fma(Mc[q + ns * c], s_coef[c], s);
   if (save) save[q] = o;
   v[r] = o + sign * s;
 }
@@ -359,12 +403,22 @@ extern "C" int pmgk_lrc_gather_rows(int64_t ns, int k, const double *M, int64_t 
   return launch_status();
 }
 
-extern "C" int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *y, double *partial, const double *scale, double *out, void *stream)
+extern "C" int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *y, double *partial, const double *scale, double *out, const double *save, double *w, void *stream)
 {
   if (ns <= 0 || k <= 0) return 0;
   const int nb = pmgk_lrc_rows_nblocks(ns);
-  hipLaunchKernelGGL(lrc_btx_rows_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, y, partial);
-  hipLaunchKernelGGL(lrc_reduce_kernel, dim3(k), dim3(64), 0, (hipStream_t)stream, nb, k, partial, scale, out);
+  if (save) hipLaunchKernelGGL((lrc_btx_rows_partial_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, y, partial, save, w);
+  else hipLaunchKernelGGL((lrc_btx_rows_partial_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, y, partial, save, w);
+  if (out) hipLaunchKernelGGL(lrc_reduce_kernel, dim3(k), dim3(64), 0, (hipStream_t)stream, nb, k, partial, scale, out); /* else: pmgk_lrc_reduce_axpy_rows adds them */
+  return launch_status();
+}
+
+/* v[rows] += sign * Mc (scale o sum of the nb partial sums pmgk_lrc_btx_rows(..., out = NULL) left); 1 <= k <= 64 */
+extern "C" int pmgk_lrc_reduce_axpy_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, int nb, const double *partial, const double *scale, double sign, double *v, double *save, void *stream)
+{
+  if (ns <= 0) return 0;
+  if (k < 1 || k > 64 || nb < 1) return 1;
+  hipLaunchKernelGGL(lrc_reduce_axpy_rows_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, nb, partial, scale, sign, v, save);
   return launch_status();
 }
 

@@ -147,7 +147,8 @@ int pmgk_lrc_mul(int k, const double *a, const double *b, double *out, void *str
 /* row-compact form (support rows only): Mc is ns x k column-major, rows[q] the position of compact row q in the vectors */
 int pmgk_lrc_mark_rows(int64_t n, int k, const double *A0, const double *A1, const double *A2, int64_t ld, unsigned char *mask, void *stream);
 int pmgk_lrc_gather_rows(int64_t ns, int k, const double *M, int64_t ld, const int64_t *rows, double *Mc, void *stream);
-int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *y, double *partial, const double *scale, double *out, void *stream);
+int pmgk_lrc_reduce_axpy_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, int nb, const double *partial, const double *scale, double sign, double *v, double *save, void *stream);
+int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *y, double *partial, const double *scale, double *out, const double *save, double *w, void *stream); /* save != NULL: also w[rows] = save */
 int pmgk_lrc_axpy_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *coef, double sign, double *v, double *save, void *stream);
 int pmgk_lrc_scatter_rows(int64_t ns, const int64_t *rows, const double *save, double *v, void *stream);
 /* fused forms (round 4): update + restore of the right-hand side; noise draw + scale + B eta;
@@ -182,6 +183,7 @@ int pmgk_xch_pull(const pmgk_xch_args *a, unsigned *err, void *stream);
 int pmgk_gather_idx(int64_t n, const int32_t *idx, const double *src, double *dst, void *stream);
 int pmgk_scatter_idx(int64_t n, const int32_t *src_idx, const int32_t *dst_idx, const double *src, double *dst, void *stream);
 int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream);
+int pmgk_fill_normal_rows_scaled(int64_t n, uint64_t seed, uint64_t sweep, const double *scale, double *xi, void *stream); /* xi = scale o z */
 
 #ifdef __cplusplus
 }

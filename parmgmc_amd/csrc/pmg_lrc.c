@@ -38,6 +38,8 @@ struct pmg_lrc_s {
      default; PMG_LRC_FUSED=1 (read when the object is built) selects the fused forms. */
   int      unfused_rhs, unfused_restore;
   int      unfused;
+  int      reduce_in_axpy; /* the partial sums of B^T y are added by the update kernel that consumes them (default); PMG_LRC_REDUCE=0: lrc_reduce_kernel */
+  int      restore_in_btx; /* the saved right-hand side entries go back in the B^T y pass of the repair (default); PMG_LRC_RESTORE=0: a kernel of their own */
   int      empty;            /* this rank's rows do not meet the support of B at all (row-distributed operator) */
   pmg_lrc_reduce_fn reduce;  /* row-distributed operator: sum of the k-vectors over the ranks */
   void             *rctx;
@@ -182,6 +184,10 @@ pmg_status pmg_lrc_build_dev(pmg_lrc *out, int32_t k, int64_t ld, const double *
     l->unfused         = !(e && e[0] == '1');
     l->unfused_rhs     = !(e && (e[0] == '1' || e[0] == '2'));
     l->unfused_restore = !(e && (e[0] == '1' || e[0] == '3'));
+    const char *er     = getenv("PMG_LRC_RESTORE");
+    l->restore_in_btx  = l->unfused_restore && !(er && er[0] == '0');
+    const char *ed     = getenv("PMG_LRC_REDUCE");
+    l->reduce_in_axpy  = !(ed && ed[0] == '0');
   }
   double sq[64];
   for (int c = 0; c < k; ++c) sq[c] = sqrt(fabs(S_host[c])); /* VecSqrtAbs(sqrtS), src/pc_mcgibbs.c:240-242 */
@@ -279,8 +285,7 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
       return PMG_SUCCESS;
     }
   }
-  PMG_KERNEL(pmgk_fill_normal_rows(l->k, nseed, counter, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w) */
-  PMG_KERNEL(pmgk_lrc_mul(l->k, l->eta, l->sqrtS, l->eta, stream));        /* VecPointwiseMult(w, w, sqrtS)   */
+  PMG_KERNEL(pmgk_fill_normal_rows_scaled(l->k, nseed, counter, l->sqrtS, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w), VecPointwiseMult(w, w, sqrtS) */
   if (l->ns) {
     PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->eta, 1.0, l->b_mod, l->saved, stream)); /* MatMultAdd(B, w, rhs, rhs) */
     return PMG_SUCCESS;
@@ -296,15 +301,20 @@ pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream)
 {
   if (l->ns && l->b_mod) {
     l->restore_pending = 1;
-    if (l->unfused_restore) PMG_CALL(lrc_flush_restore(l, stream));
+    if (l->unfused_restore && !l->restore_in_btx) PMG_CALL(lrc_flush_restore(l, stream));
   }
   return PMG_SUCCESS;
 }
 
 /* wk = scale o (B^T x) over the support rows: partial sums per block of rows, then their sum in a fixed order */
-static pmg_status lrc_btx_compact(pmg_lrc l, const double *x_lay, const double *scale, void *stream)
+/* up to 8 columns (two per wavefront of the update's workgroups); measured at 257^3: k = 3 0.754 -> 0.730 ms per sample, but
+   k = 17 1.249 -> 1.337: five rounds of column sums in every block cost more than the launch they replace */
+static int lrc_reduce_later(pmg_lrc l) { return l->reduce_in_axpy && !l->reduce && l->k <= 8; }
+
+/* partial_only: the sums stay per block in l->partial for pmgk_lrc_reduce_axpy_rows */
+static pmg_status lrc_btx_compact(pmg_lrc l, const double *x_lay, const double *scale, const double *save, double *w, int partial_only, void *stream)
 {
-  PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, x_lay, l->partial, scale, l->wk, stream));
+  PMG_KERNEL(pmgk_lrc_btx_rows(l->ns, l->k, l->Bc, l->rows, x_lay, l->partial, scale, partial_only ? NULL : l->wk, save, w, stream));
   return PMG_SUCCESS;
 }
 
@@ -322,9 +332,11 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
       PMG_KERNEL(pmgk_lrc_btx_axpy_small(l->ns, l->k, l->Bc, l->rows, x_lay, l->S, l->wk, l->ns, l->Bc, l->rows, -1.0, r_lay, NULL, NULL, stream));
       return PMG_SUCCESS;
     }
-    PMG_CALL(lrc_btx_compact(l, x_lay, l->S, stream));
+    const int later = lrc_reduce_later(l);
+    PMG_CALL(lrc_btx_compact(l, x_lay, l->S, NULL, NULL, later, stream));
     if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream)); /* S scales every partial sum alike */
-    PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->wk, -1.0, r_lay, NULL, stream));
+    if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(l->ns, l->k, l->Bc, l->rows, pmgk_lrc_rows_nblocks(l->ns), l->partial, l->S, -1.0, r_lay, NULL, stream));
+    else PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->wk, -1.0, r_lay, NULL, stream));
     return PMG_SUCCESS;
   }
   PMG_KERNEL(pmgk_lrc_btx(l->ld, l->k, l->B, l->ld, x_lay, l->partial, l->S, l->wk, stream));
@@ -378,12 +390,14 @@ pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc lf, pmg_lrc lc, const double 
     PMG_KERNEL(pmgk_lrc_btx_axpy_small(lf->ns, lf->k, lf->Bc, lf->rows, x_fine_lay, lf->S, lf->wk, lc->ns, lc->Bc, lc->rows, -1.0, b_coarse_lay, NULL, NULL, stream));
     return PMG_SUCCESS;
   }
+  const int later = !lf->empty && lf->ns && !lc->empty && lc->ns && lrc_reduce_later(lf);
   if (lf->empty) PMG_HIP(hipMemsetAsync(lf->wk, 0, sizeof(double) * (size_t)lf->k, (hipStream_t)stream));
-  else if (lf->ns) PMG_CALL(lrc_btx_compact(lf, x_fine_lay, lf->S, stream));
+  else if (lf->ns) PMG_CALL(lrc_btx_compact(lf, x_fine_lay, lf->S, NULL, NULL, later, stream));
   else PMG_KERNEL(pmgk_lrc_btx(lf->ld, lf->k, lf->B, lf->ld, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
   if (lf->reduce) PMG_CALL(lf->reduce(lf->rctx, lf->wk, lf->k, stream));
   if (lc->empty) return PMG_SUCCESS; /* none of B_c's rows on this rank */
-  if (lc->ns) PMG_KERNEL(pmgk_lrc_axpy_rows(lc->ns, lc->k, lc->Bc, lc->rows, lf->wk, -1.0, b_coarse_lay, NULL, stream));
+  if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(lc->ns, lc->k, lc->Bc, lc->rows, pmgk_lrc_rows_nblocks(lf->ns), lf->partial, lf->S, -1.0, b_coarse_lay, NULL, stream));
+  else if (lc->ns) PMG_KERNEL(pmgk_lrc_axpy_rows(lc->ns, lc->k, lc->Bc, lc->rows, lf->wk, -1.0, b_coarse_lay, NULL, stream));
   else PMG_KERNEL(pmgk_lrc_axpy_cols(lc->ld, lc->k, lc->B, lc->ld, lf->wk, -1.0, b_coarse_lay, b_coarse_lay, stream));
   return PMG_SUCCESS;
 }
@@ -403,9 +417,12 @@ pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
     if (l->restore_pending && !save) PMG_CALL(lrc_flush_restore(l, stream));
     if (lrc_small(l, l->ns)) PMG_KERNEL(pmgk_lrc_btx_axpy_small(l->ns, l->k, l->Bc, l->rows, y_lay, NULL, l->wk, l->ns, l->Bbc[d], l->rows, -1.0, y_lay, save, bmod, stream));
     else {
-      PMG_CALL(lrc_btx_compact(l, y_lay, NULL, stream));
+      const int early = save && l->restore_in_btx; /* in the first pass over the support rows instead of the last */
+      const int later = lrc_reduce_later(l) && (early || !save);
+      PMG_CALL(lrc_btx_compact(l, y_lay, NULL, early ? save : NULL, early ? bmod : NULL, later, stream));
       if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream));
-      if (save) PMG_KERNEL(pmgk_lrc_axpy_restore_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, save, bmod, stream));
+      if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, pmgk_lrc_rows_nblocks(l->ns), l->partial, NULL, -1.0, y_lay, NULL, stream));
+      else if (save && !early) PMG_KERNEL(pmgk_lrc_axpy_restore_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, save, bmod, stream));
       else PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, NULL, stream));
     }
     if (save) {

@@ -125,8 +125,7 @@ pmg_status pmg_woodbury_finish(pmg_woodbury w)
 pmg_status pmg_woodbury_noisy_rhs(pmg_woodbury w, const double *b_dev, double *w_dev, uint64_t seed, uint64_t counter, void *stream)
 {
   PMG_CHECK(w && (w->n == 0 || (b_dev && w_dev)), PMG_ERR_ARG_NULL, "null argument");
-  PMG_KERNEL(pmgk_fill_normal_rows(w->k, seed, counter, w->wk, stream)); /* VecSetRandomStandardNormal(wb->wk) */
-  PMG_KERNEL(pmgk_lrc_mul(w->k, w->wk, w->S_sqrt, w->wk, stream));       /* VecPointwiseMult */
+  PMG_KERNEL(pmgk_fill_normal_rows_scaled(w->k, seed, counter, w->S_sqrt, w->wk, stream)); /* VecSetRandomStandardNormal(wb->wk), VecPointwiseMult */
   if (w->n) PMG_KERNEL(pmgk_lrc_axpy_cols(w->n, w->k, w->B, w->n, w->wk, 1.0, b_dev, w_dev, stream)); /* MatMultAdd(B, wk, b, w) */
   return PMG_SUCCESS;
 }
