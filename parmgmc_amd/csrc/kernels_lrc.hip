@@ -208,6 +208,64 @@ __global__ __launch_bounds__(256) void lrc_reduce_axpy_rows_kernel(int64_t ns, i
   v[r] = o + sign * s;
 }
 
+// The repair of a sweep that is followed by a residual (the down leg of the V-cycle): lrc_reduce_axpy_rows_kernel's update
+// v[rows] += sign * Mb coef AND, with the new values still in registers, the partial sums of Mc^T v that the residual's low-rank
+// term starts with (lrc_btx_rows_partial_kernel on the same rows) -- one pass less over the support rows and one launch less per
+// level.  Blocks of 256 * PMG_LRC_RPT rows, a thread owns the rows q0 + 256 i, the sums in lrc_btx_rows_partial_kernel's order:
+// partial_out holds the same bits as that kernel's output on the updated vector.  k <= 8.
+__global__ __launch_bounds__(256) void lrc_reduce_axpy_btx_rows_kernel(int64_t ns, int k, const double *__restrict__ Mb, const int64_t *__restrict__ rows, int nb, const double *__restrict__ partial_in, double sign, double *__restrict__ v, const double *__restrict__ Mc, double *__restrict__ partial_out)
+{
+  __shared__ double s_coef[8];
+  __shared__ double red[8][4];
+  const int64_t     q0 = (int64_t)blockIdx.x * (256 * PMG_LRC_RPT) + threadIdx.x;
+  int64_t           rr[PMG_LRC_RPT];
+  double            o[PMG_LRC_RPT], m[PMG_LRC_RPT], yv[PMG_LRC_RPT];
+#pragma unroll
+  for (int i = 0; i < PMG_LRC_RPT; ++i) {
+    const int64_t q = q0 + 256 * i;
+    rr[i]           = q < ns ? rows[q] : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < PMG_LRC_RPT; ++i) {
+    const int64_t q = q0 + 256 * i;
+    m[i]            = q < ns ? Mb[q] : 0.0;
+  }
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = wv; c < k; c += 4) {
+    double s = 0.0;
+    for (int b = lane; b < nb; b += 64) s += partial_in[(int64_t)b * k + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) s_coef[c] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < PMG_LRC_RPT; ++i) o[i] = rr[i] >= 0 ? v[rr[i]] : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PMG_LRC_RPT; ++i) {
+    const int64_t q = q0 + 256 * i;
+    double        a = fma(m[i], s_coef[0], 0.0);
+    if (q < ns)
+      for (int c = 1; c < k; ++c) a = fma(Mb[q + ns * c], s_coef[c], a);
+    yv[i] = o[i] + sign * a;
+    if (q < ns) v[rr[i]] = yv[i];
+  }
+  for (int c = 0; c < k; ++c) {
+    const double *col = Mc + ns * (int64_t)c;
+    double        s   = 0.0;
+#pragma unroll
+    for (int i = 0; i < PMG_LRC_RPT; ++i) {
+      const int64_t q = q0 + 256 * i;
+      if (q < ns) s = fma(col[q], yv[i], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[c][wv] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < k) partial_out[(int64_t)blockIdx.x * k + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 __global__ __launch_bounds__(256) void lrc_scatter_rows_kernel(int64_t ns, const int64_t *__restrict__ rows, const double *__restrict__ save, double *__restrict__ v)
 {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -419,6 +477,17 @@ extern "C" int pmgk_lrc_reduce_axpy_rows(int64_t ns, int k, const double *Mc, co
   if (ns <= 0) return 0;
   if (k < 1 || k > 64 || nb < 1) return 1;
   hipLaunchKernelGGL(lrc_reduce_axpy_rows_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ns, k, Mc, rows, nb, partial, scale, sign, v, save);
+  return launch_status();
+}
+
+/* pmgk_lrc_reduce_axpy_rows(Mb, partial_in, no scale) and, on the updated v, the partial sums pmgk_lrc_btx_rows(Mc, ..., out = NULL)
+   would leave in partial_out (nb = pmgk_lrc_rows_nblocks(ns) blocks each); 1 <= k <= 8 */
+extern "C" int pmgk_lrc_reduce_axpy_btx_rows(int64_t ns, int k, const double *Mb, const int64_t *rows, const double *partial_in, double sign, double *v, const double *Mc, double *partial_out, void *stream)
+{
+  if (ns <= 0) return 0;
+  if (k < 1 || k > 8) return 1;
+  const int nb = pmgk_lrc_rows_nblocks(ns);
+  hipLaunchKernelGGL(lrc_reduce_axpy_btx_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, ns, k, Mb, rows, nb, partial_in, sign, v, Mc, partial_out);
   return launch_status();
 }
 

@@ -148,6 +148,7 @@ int pmgk_lrc_mul(int k, const double *a, const double *b, double *out, void *str
 int pmgk_lrc_mark_rows(int64_t n, int k, const double *A0, const double *A1, const double *A2, int64_t ld, unsigned char *mask, void *stream);
 int pmgk_lrc_gather_rows(int64_t ns, int k, const double *M, int64_t ld, const int64_t *rows, double *Mc, void *stream);
 int pmgk_lrc_reduce_axpy_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, int nb, const double *partial, const double *scale, double sign, double *v, double *save, void *stream);
+int pmgk_lrc_reduce_axpy_btx_rows(int64_t ns, int k, const double *Mb, const int64_t *rows, const double *partial_in, double sign, double *v, const double *Mc, double *partial_out, void *stream);
 int pmgk_lrc_btx_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *y, double *partial, const double *scale, double *out, const double *save, double *w, void *stream); /* save != NULL: also w[rows] = save */
 int pmgk_lrc_axpy_rows(int64_t ns, int k, const double *Mc, const int64_t *rows, const double *coef, double sign, double *v, double *save, void *stream);
 int pmgk_lrc_scatter_rows(int64_t ns, const int64_t *rows, const double *save, double *v, void *stream);

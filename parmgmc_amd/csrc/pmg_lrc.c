@@ -38,6 +38,11 @@ struct pmg_lrc_s {
      default; PMG_LRC_FUSED=1 (read when the object is built) selects the fused forms. */
   int      unfused_rhs, unfused_restore;
   int      unfused;
+  /* the repair in front of a residual (down leg of a V-cycle, pmg_lrc_expect_residual) also leaves the partial sums of B^T y_new
+     in partial2; the residual's low-rank term then starts from them instead of passing over the support rows again */
+  double       *partial2;
+  const double *bty_vec; /* the vector partial2 belongs to, NULL = none */
+  int           want_bty, bty_in_post; /* PMG_LRC_BTY=1 (not the default: no gain measured) */
   int      reduce_in_axpy; /* the partial sums of B^T y are added by the update kernel that consumes them (default); PMG_LRC_REDUCE=0: lrc_reduce_kernel */
   int      restore_in_btx; /* the saved right-hand side entries go back in the B^T y pass of the repair (default); PMG_LRC_RESTORE=0: a kernel of their own */
   int      empty;            /* this rank's rows do not meet the support of B at all (row-distributed operator) */
@@ -57,6 +62,7 @@ void pmg_lrc_destroy(pmg_lrc *p)
   pmg_dev_free(l->wk);
   pmg_dev_free(l->eta);
   pmg_dev_free(l->partial);
+  pmg_dev_free(l->partial2);
   pmg_dev_free(l->beff);
   pmg_dev_free(l->col);
   pmg_dev_free(l->rows);
@@ -151,6 +157,7 @@ static pmg_status lrc_compact(pmg_lrc l)
     l->partial = NULL;
     st         = pmg_dev_alloc((void **)&l->partial, sizeof(double) * (size_t)pmgk_lrc_rows_nblocks(ns) * (size_t)l->k);
   }
+  if (!st) st = pmg_dev_alloc((void **)&l->partial2, sizeof(double) * (size_t)pmgk_lrc_rows_nblocks(ns) * (size_t)l->k);
   if (!st && (pmgk_lrc_gather_rows(ns, l->k, l->B, l->ld, l->rows, l->Bc, NULL) || pmgk_lrc_gather_rows(ns, l->k, l->Bb[0], l->ld, l->rows, l->Bbc[0], NULL) || pmgk_lrc_gather_rows(ns, l->k, l->Bb[1], l->ld, l->rows, l->Bbc[1], NULL))) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "kernel launch failed");
   if (!st && hipDeviceSynchronize() != hipSuccess) st = pmg_set_error(PMG_ERR_GPU, __FILE__, __LINE__, "device error while compacting the low-rank factors");
   if (st) return st;
@@ -188,6 +195,8 @@ pmg_status pmg_lrc_build_dev(pmg_lrc *out, int32_t k, int64_t ld, const double *
     l->restore_in_btx  = l->unfused_restore && !(er && er[0] == '0');
     const char *ed     = getenv("PMG_LRC_REDUCE");
     l->reduce_in_axpy  = !(ed && ed[0] == '0');
+    const char *eb     = getenv("PMG_LRC_BTY");
+    l->bty_in_post     = eb && eb[0] == '1'; /* measured at 257^3, k = 3: 0.741-0.746 ms per sample with it, 0.737-0.745 without (one launch less per level, but blocks of 1024 rows with the update's and the sums' fetch chains one behind the other): not the default */
   }
   double sq[64];
   for (int c = 0; c < k; ++c) sq[c] = sqrt(fabs(S_host[c])); /* VecSqrtAbs(sqrtS), src/pc_mcgibbs.c:240-242 */
@@ -275,6 +284,7 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
     return PMG_SUCCESS;
   }
   const uint64_t nseed = seed + 0x632BE59BD9B4E019ull;
+  l->bty_vec           = NULL;
   if (l->ns) {
     PMG_CALL(lrc_flush_restore(l, stream));
     PMG_CHECK(!l->b_mod, PMG_ERR_ARG_WRONGSTATE, "pmg_lrc_rhs_done missing");
@@ -333,9 +343,10 @@ pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, v
       return PMG_SUCCESS;
     }
     const int later = lrc_reduce_later(l);
-    PMG_CALL(lrc_btx_compact(l, x_lay, l->S, NULL, NULL, later, stream));
+    const int have  = later && l->bty_vec == x_lay; /* the repair in front left the partial sums of B^T x */
+    if (!have) PMG_CALL(lrc_btx_compact(l, x_lay, l->S, NULL, NULL, later, stream));
     if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream)); /* S scales every partial sum alike */
-    if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(l->ns, l->k, l->Bc, l->rows, pmgk_lrc_rows_nblocks(l->ns), l->partial, l->S, -1.0, r_lay, NULL, stream));
+    if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(l->ns, l->k, l->Bc, l->rows, pmgk_lrc_rows_nblocks(l->ns), have ? l->partial2 : l->partial, l->S, -1.0, r_lay, NULL, stream));
     else PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->wk, -1.0, r_lay, NULL, stream));
     return PMG_SUCCESS;
   }
@@ -373,6 +384,15 @@ void pmg_lrc_get_sizes(pmg_lrc l, int32_t *k, int64_t *ns, int *dense)
   if (dense) *dense = is_dense;
 }
 
+/* on: the sweeps that follow are the pre-smoothing of a V-cycle level -- a residual of the same vector comes next (off: whatever
+   the last repair left behind is forgotten) */
+void pmg_lrc_expect_residual(pmg_lrc l, int on)
+{
+  if (!l) return;
+  l->want_bty = on;
+  if (!on) l->bty_vec = NULL;
+}
+
 /* 1: the update lives on one device (no reduction over ranks, rows on this rank) */
 int pmg_lrc_is_local(pmg_lrc l) { return l && !l->reduce && !l->empty; }
 
@@ -391,12 +411,14 @@ pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc lf, pmg_lrc lc, const double 
     return PMG_SUCCESS;
   }
   const int later = !lf->empty && lf->ns && !lc->empty && lc->ns && lrc_reduce_later(lf);
+  const int have = later && lf->bty_vec == x_fine_lay;
   if (lf->empty) PMG_HIP(hipMemsetAsync(lf->wk, 0, sizeof(double) * (size_t)lf->k, (hipStream_t)stream));
-  else if (lf->ns) PMG_CALL(lrc_btx_compact(lf, x_fine_lay, lf->S, NULL, NULL, later, stream));
+  else if (have) { /* the repair in front left the partial sums of B_f^T x */
+  } else if (lf->ns) PMG_CALL(lrc_btx_compact(lf, x_fine_lay, lf->S, NULL, NULL, later, stream));
   else PMG_KERNEL(pmgk_lrc_btx(lf->ld, lf->k, lf->B, lf->ld, x_fine_lay, lf->partial, lf->S, lf->wk, stream));
   if (lf->reduce) PMG_CALL(lf->reduce(lf->rctx, lf->wk, lf->k, stream));
   if (lc->empty) return PMG_SUCCESS; /* none of B_c's rows on this rank */
-  if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(lc->ns, lc->k, lc->Bc, lc->rows, pmgk_lrc_rows_nblocks(lf->ns), lf->partial, lf->S, -1.0, b_coarse_lay, NULL, stream));
+  if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(lc->ns, lc->k, lc->Bc, lc->rows, pmgk_lrc_rows_nblocks(lf->ns), have ? lf->partial2 : lf->partial, lf->S, -1.0, b_coarse_lay, NULL, stream));
   else if (lc->ns) PMG_KERNEL(pmgk_lrc_axpy_rows(lc->ns, lc->k, lc->Bc, lc->rows, lf->wk, -1.0, b_coarse_lay, NULL, stream));
   else PMG_KERNEL(pmgk_lrc_axpy_cols(lc->ld, lc->k, lc->B, lc->ld, lf->wk, -1.0, b_coarse_lay, b_coarse_lay, stream));
   return PMG_SUCCESS;
@@ -406,6 +428,7 @@ pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc lf, pmg_lrc lc, const double 
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
 {
   const int d = dir == PMG_SOR_FORWARD_SWEEP ? 0 : 1;
+  l->bty_vec  = NULL;
   if (l->empty) {
     PMG_HIP(hipMemsetAsync(l->wk, 0, sizeof(double) * (size_t)l->k, (hipStream_t)stream));
     return l->reduce(l->rctx, l->wk, l->k, stream);
@@ -421,7 +444,10 @@ pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream)
       const int later = lrc_reduce_later(l) && (early || !save);
       PMG_CALL(lrc_btx_compact(l, y_lay, NULL, early ? save : NULL, early ? bmod : NULL, later, stream));
       if (l->reduce) PMG_CALL(l->reduce(l->rctx, l->wk, l->k, stream));
-      if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, pmgk_lrc_rows_nblocks(l->ns), l->partial, NULL, -1.0, y_lay, NULL, stream));
+      if (later && l->want_bty && l->bty_in_post) {
+        PMG_KERNEL(pmgk_lrc_reduce_axpy_btx_rows(l->ns, l->k, l->Bbc[d], l->rows, l->partial, -1.0, y_lay, l->Bc, l->partial2, stream));
+        l->bty_vec = y_lay;
+      } else if (later) PMG_KERNEL(pmgk_lrc_reduce_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, pmgk_lrc_rows_nblocks(l->ns), l->partial, NULL, -1.0, y_lay, NULL, stream));
       else if (save && !early) PMG_KERNEL(pmgk_lrc_axpy_restore_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, save, bmod, stream));
       else PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bbc[d], l->rows, l->wk, -1.0, y_lay, NULL, stream));
     }

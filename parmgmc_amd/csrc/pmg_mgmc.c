@@ -1698,8 +1698,12 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
       if (Lv->x2 && st27_use_pair(Lv) && h->nu >= 1) Lv->x_unset = 1; /* (also under a low-rank update: the noise term changes b, the repair acts on the swept iterate -- round 3 excluded those levels without need and paid three zero fills and twelve full phase launches per 257^3 sample) */
       else PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
     }
-    PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
     pmg_lrc flrc = Lv->is_grid ? (Lv->lrc ? Lv->lrc : pmg_grid_lrc(Lv->g)) : NULL; /* the grid level's low-rank update (held by the level on a slab hierarchy, by the grid object otherwise) */
+    pmg_lrc slrc = Lv->is_grid ? flrc : Lv->lrc;
+    pmg_lrc_expect_residual(slrc, 1); /* the last repair of the pre-smoothing also starts the residual's low-rank term */
+    const pmg_status sst = mg_smooth(h, l, seed, &ctr[l], stream);
+    pmg_lrc_expect_residual(slrc, sst == PMG_SUCCESS); /* (an error: forget) */
+    PMG_CALL(sst);
     if (Lv->is_grid && Lv->grid_transfer && !Lv->distributed && !Lv->cpos_dev && !h->no_fused && (!flrc || (pmg_lrc_is_local(flrc) && Cc->is_st27 && pmg_lrc_is_local(Cc->lrc)))) { /* b_{l-1} = P^T (b - A x) in one pass */
       const pmgk_st27_dims CD = level_dims(Cc);
       int                  done = 0;
@@ -1743,6 +1747,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     const int first = h->sweep_type == PMG_SOR_BACKWARD_SWEEP ? 1 : 0;
     const int only  = (h->omega == 1.0 && h->nu >= 1 && !no_skip) ? 1 - first : -1;
     PMG_CALL(mg_prolong_add(h, l, h->lv[l - 1].x, Lv->x, only, stream));
+    pmg_lrc_expect_residual(Lv->lrc ? Lv->lrc : (Lv->is_grid ? pmg_grid_lrc(Lv->g) : NULL), 0); /* no residual behind the post-smoothing */
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
   }
   return PMG_SUCCESS;

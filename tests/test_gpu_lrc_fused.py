@@ -3,7 +3,11 @@ update that also puts the right-hand side back, one workgroup for small supports
 built -- measured 2 % SLOWER than the chain of small kernels at 257^3, so not the default, pmg_lrc.c).  The fused kernels
 keep every sum in the order of the kernels they replace, so whole chains must be BIT-IDENTICAL to the chain of small
 kernels -- the form tests/test_lrc.py and tests/test_gpu_benchsize_lowrank.py pin against the oracle (reference src/mc_sor.c:101-112,
-src/pc_mcgibbs.c:130-140, src/pc_sorgibbs.c:86-101)."""
+src/pc_mcgibbs.c:130-140, src/pc_sorgibbs.c:86-101).
+
+Also the two folds that ARE the default since round 4 (the restore of b in the B^T y pass, the partial sums added by the update
+kernel: PMG_LRC_RESTORE=0, PMG_LRC_REDUCE=0 switch them off) and a third that is not (PMG_LRC_BTY=1: the repair in front of a
+residual leaves the partial sums of B^T y_new for it; no gain measured), whole V-cycle chains bit for bit."""
 import numpy as np
 import pytest
 
@@ -92,3 +96,41 @@ def test_fused_chain_on_an_aij_operator(monkeypatch):
         assert np.array_equal(host(bd), b)
         outs.append(host(yd).copy())
     assert np.array_equal(outs[0], outs[1])
+
+
+def _vcycle_chain(monkeypatch, env, grid, levels, B, S, b, y0, sweep, its):
+    from parmgmc_amd import MGMC
+
+    for key in ("PMG_LRC_FUSED", "PMG_LRC_RESTORE", "PMG_LRC_REDUCE", "PMG_LRC_BTY"):
+        monkeypatch.delenv(key, raising=False)
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    mg = MGMC(*grid, 2.0, levels)
+    mg.set_smoother(True, 1.0, sweep, 1)
+    mg.set_lowrank(B, S)
+    mg.setup()
+    bd, yd = dev(b), dev(y0)
+    mg.sample(bd, yd, its, seed=23, counter0=0)
+    assert np.array_equal(host(bd), b), "the right-hand side must come back bit for bit"
+    return host(yd).copy()
+
+
+@pytest.mark.parametrize("k", [3, 8, 11])
+@pytest.mark.parametrize("sweep", [O.SOR_FORWARD, O.SOR_SYMMETRIC])
+def test_default_folds_equal_their_switched_off_forms_bit_for_bit(monkeypatch, k, sweep):
+    """65^3 x 33, 4 levels: several blocks of support rows on the two finest levels; k = 8 is the last rank whose partial sums
+    the update kernel adds itself, k = 11 takes lrc_reduce_kernel either way"""
+    grid, levels = (65, 65, 33), 4
+    n = int(np.prod(grid))
+    rng = np.random.default_rng(100 + k)
+    ctr = [tuple(rng.uniform(0.25, 0.75, 3)) for _ in range(k)]
+    lo, hi = {3: (0.18, 0.22), 8: (0.12, 0.15), 11: (0.10, 0.13)}[k]
+    B = ball_matrix(grid, ctr, list(rng.uniform(lo, hi, k)))
+    assert 4096 < int((np.abs(B).sum(1) > 0).sum()) < n // 6  # row-compact form, several blocks
+    S = rng.uniform(20.0, 90.0, k)
+    b, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    want = _vcycle_chain(monkeypatch, {"PMG_LRC_RESTORE": "0", "PMG_LRC_REDUCE": "0"}, grid, levels, B, S, b, y0, sweep, 3)
+    assert np.isfinite(want).all()
+    for env in ({}, {"PMG_LRC_BTY": "1"}, {"PMG_LRC_REDUCE": "0"}, {"PMG_LRC_RESTORE": "0"}, {"PMG_LRC_BTY": "1", "PMG_LRC_RESTORE": "0"}):
+        got = _vcycle_chain(monkeypatch, env, grid, levels, B, S, b, y0, sweep, 3)
+        assert np.array_equal(got, want), env
