@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void csr_spmv_kernel(int32_t nrows, const int3
 }
 
 template <bool ACC>
-__global__ __launch_bounds__(256) void csr_spmv_rows_kernel(int32_t nrows, const int32_t *__restrict__ rowpos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y)
+__global__ __launch_bounds__(256) void csr_spmv_rows_kernel(int32_t nrows, const int32_t *__restrict__ rowpos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ zero)
 {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void csr_spmv_rows_kernel(int32_t nrows, const
       if (kb + q < k1) sum = sum + a[q] * xv[q];
   }
   y[o] = ACC ? yo + sum : sum;
+  if (zero) zero[o] = 0.0; // the restriction of a V-cycle also sets the coarse level's zero guess (a fill kernel less per level)
 }
 
 __global__ void axpy_kernel(int64_t n, double alpha, const double *__restrict__ x, double *__restrict__ y)
@@ -237,12 +238,12 @@ extern "C" int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t
   return launch_status();
 }
 
-extern "C" int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, void *stream)
+extern "C" int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, double *zero, void *stream)
 {
   if (nrows <= 0) return 0;
   const dim3 grid((nrows + 255) / 256), block(256);
-  if (accumulate) hipLaunchKernelGGL((csr_spmv_rows_kernel<true>), grid, block, 0, (hipStream_t)stream, nrows, rowpos, rowptr, colidx, vals, x, y);
-  else hipLaunchKernelGGL((csr_spmv_rows_kernel<false>), grid, block, 0, (hipStream_t)stream, nrows, rowpos, rowptr, colidx, vals, x, y);
+  if (accumulate) hipLaunchKernelGGL((csr_spmv_rows_kernel<true>), grid, block, 0, (hipStream_t)stream, nrows, rowpos, rowptr, colidx, vals, x, y, zero);
+  else hipLaunchKernelGGL((csr_spmv_rows_kernel<false>), grid, block, 0, (hipStream_t)stream, nrows, rowpos, rowptr, colidx, vals, x, y, zero);
   return launch_status();
 }
 

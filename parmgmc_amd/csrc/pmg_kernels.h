@@ -95,7 +95,7 @@ int pmgk_permute_out(int32_t ld, const int32_t *orig, const double *perm, double
 int pmgk_csr_spmv(int32_t nrows, const int32_t *rowptr, const int32_t *colidx, const double *vals, double alpha, const double *x, double beta, double *y, void *stream);
 /* y[rowpos[r]] (+)= alpha * sum_k vals[k] x[colidx[k]] over the rows of a CSR block whose output positions are
    given explicitly (transfer operators between level layouts); accumulate != 0 adds to y */
-int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, void *stream);
+int pmgk_csr_spmv_rows(int32_t nrows, const int32_t *rowpos, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *x, double *y, int accumulate, double *zero, void *stream); /* zero != NULL: zero[rowpos[r]] = 0 as well */
 /* dense lower Cholesky in place + W = L^-1 on the device (npad multiple of 32; MFMA f64 trailing updates) */
 int pmgk_potrf_inverse(int32_t npad, double *A_colmajor, double *W_colmajor, double *T_scratch, double *Dinv_scratch, int *info_dev, void *stream);
 int pmgk_pack_rowmajor(int32_t n, const double *in_colmajor, int64_t ld, int transpose, double *out_rowmajor, void *stream);

@@ -42,6 +42,7 @@ typedef struct {
   pmg_mcsor mc;
   int64_t   ld;
   double   *b, *x, *r;
+  int       x_zeroed; /* the restriction kernel has set the zero guess already */
   int       x_unset; /* the iterate is zero but the memset was skipped: the next out-of-place sweep starts from NULL */
   double   *y2lo, *y2hi; /* z-slab grid level: the iterate's planes kz0 - 2 and kz0 + nz + 1 (colour 0 plane, colour 1 plane) for the fused residual + restriction */
   int       rr_slab;     /* ... which every rank can run (agreed from the slab cuts) */
@@ -917,7 +918,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
       for (int32_t c = 0; c < h->lrc_k; ++c) {
         double *bf = Bdev + (size_t)U->ld * c, *bc = Bc + (size_t)Cc->ld * c;
         PMG_CALL(pmg_distmcsor_refresh_layout(U->dm, bf, NULL)); /* the rows of P^T read other ranks' rows of B */
-        PMG_KERNEL(pmgk_csr_spmv_rows(U->R_nrows, U->R_rowpos, U->R_rowptr, U->R_col, U->R_val, bf, bc, 0, NULL));
+        PMG_KERNEL(pmgk_csr_spmv_rows(U->R_nrows, U->R_rowpos, U->R_rowptr, U->R_col, U->R_val, bf, bc, 0, NULL, NULL));
         if (l == h->rb_fold) PMG_CALL(rb_fold_allgather(h, bc, NULL)); /* the replicated level below takes the whole column */
       }
       /* the refresh left copies on the ghost rows of the fine block: back to zeros there (B counts every row once) -- not
@@ -1602,7 +1603,17 @@ static pmg_status mg_restrict(pmg_mgmc h, int l, double *r_fine, double *b_coars
     PMG_KERNEL(pmgk_st27_restrict(&FD, &CD, r_fine, bc, stream));
   } else {
     if (Lv->dm) PMG_CALL(pmg_distmcsor_refresh_layout(Lv->dm, r_fine, stream)); /* row block: the rows of P^T read r on other ranks' rows */
-    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, r_fine, b_coarse, 0, stream));
+    /* inside a cycle on one device the restriction also sets the zero guess of the coarse level: its rows are the rows of P^T, the
+       padding of the layout is never written (zero since the allocation) -- one fill kernel less per level (PMG_MG_FUSED_ZERO=0) */
+    static int fz = -1;
+    if (fz < 0) {
+      const char *e = getenv("PMG_MG_FUSED_ZERO");
+      fz            = e ? atoi(e) : 1;
+    }
+    const int needs_zero = l - 1 >= 1 || h->coarse_type != 0;
+    double   *zero = fz && needs_zero && !h->dist && !Lv->dm && !Cc->dm && b_coarse == Cc->b && Cc->mc && Lv->R_nrows == Cc->n ? Cc->x : NULL;
+    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->R_nrows, Lv->R_rowpos, Lv->R_rowptr, Lv->R_col, Lv->R_val, r_fine, b_coarse, 0, zero, stream));
+    if (zero) Cc->x_zeroed = 1;
     if (Lv->dm && l == h->rb_fold) PMG_CALL(rb_fold_allgather(h, b_coarse, stream)); /* the replicated level below: every rank needs the whole right-hand side */
   }
   if (fold) {
@@ -1678,7 +1689,7 @@ static pmg_status mg_prolong_add(pmg_mgmc h, int l, const double *e_coarse, doub
     const pmgk_st27_dims FD = level_dims(Lv), CD = level_dims(Cc);
     PMG_KERNEL(pmgk_st27_prolong_add(&FD, &CD, Lv->kz0 - glo, Lv->nzl + glo + ghi, e_coarse, x_fine, stream));
   } else {
-    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, e_coarse, x_fine, 1, stream));
+    PMG_KERNEL(pmgk_csr_spmv_rows(Lv->P_nrows, Lv->P_rowpos, Lv->P_rowptr, Lv->P_col, Lv->P_val, e_coarse, x_fine, 1, NULL, stream));
   }
   return PMG_SUCCESS;
 }
@@ -1691,11 +1702,13 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
   uint64_t  ctr[64];
   PMG_CHECK(h->nlevels <= 64, PMG_ERR_ARG_OUTOFRANGE, "too many levels");
   for (int l = 0; l <= top; ++l) ctr[l] = sample * MG_DRAWS_PER_SAMPLE;
+  for (int l = 0; l <= top; ++l) h->lv[l].x_zeroed = 0; /* (a cycle that ended in an error may have left one set) */
   for (int l = top; l >= 1; --l) {
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
     if (l < top || !top_has_guess) {
       /* class-stencil levels with the out-of-place sweep: no memset, the first sweep is told that its input is zero */
-      if (Lv->x2 && st27_use_pair(Lv) && h->nu >= 1) Lv->x_unset = 1; /* (also under a low-rank update: the noise term changes b, the repair acts on the swept iterate -- round 3 excluded those levels without need and paid three zero fills and twelve full phase launches per 257^3 sample) */
+      if (Lv->x_zeroed) Lv->x_zeroed = 0;
+      else if (Lv->x2 && st27_use_pair(Lv) && h->nu >= 1) Lv->x_unset = 1; /* (also under a low-rank update: the noise term changes b, the repair acts on the swept iterate -- round 3 excluded those levels without need and paid three zero fills and twelve full phase launches per 257^3 sample) */
       else PMG_KERNEL(pmgk_fill_zero(Lv->x, Lv->ld, stream));
     }
     pmg_lrc flrc = Lv->is_grid ? (Lv->lrc ? Lv->lrc : pmg_grid_lrc(Lv->g)) : NULL; /* the grid level's low-rank update (held by the level on a slab hierarchy, by the grid object otherwise) */
@@ -1733,7 +1746,8 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     if (h->coarse_type == 0) {
       PMG_CALL(pmg_chol_sample(h->chol, C0->b + C0->off, C0->x + C0->off, 1, level_seed(seed, 0), ctr[0], stream));
     } else {
-      PMG_KERNEL(pmgk_fill_zero(C0->x, C0->ld, stream));
+      if (C0->x_zeroed) C0->x_zeroed = 0;
+      else PMG_KERNEL(pmgk_fill_zero(C0->x, C0->ld, stream));
       if (C0->is_st27) PMG_CALL(st27_sample(h, C0, h->coarse_its, level_seed(seed, 0), &ctr[0], stream));
       else PMG_CALL(pmg_mcsor_sample_layout(C0->mc, C0->b, C0->x, h->coarse_its, h->scaled, level_seed(seed, 0), ctr[0], &ctr[0], stream));
     }
