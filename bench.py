@@ -178,6 +178,32 @@ def mgmc_secondary(n: int = 257, levels: int = 5, its: int = 40) -> dict:
     return {"workload": f"{n}^3 DMDA, {levels}-level V-cycle MGMC sample (sorgibbs 1+1, cholsampler on {(n - 1) // 2 ** (levels - 1) + 1}^3)", "value": 1e3 / ms, "unit": "samples/s", "ms_per_sample": ms, "setup_s": setup_s, "roofline": cycle_roofline(alg, ms, f"mgmc_{n}_{levels}"), "algorithmic_bytes_per_unknown": alg / n ** 3, "algorithmic_bytes_per_level": [float(x) for x in per], "finite": bool(torch.isfinite(y).all().item())}
 
 
+def stream_ceiling(n_doubles: int, reps: int = 20) -> dict:
+    """The bandwidth a kernel with the colour sweep's access mix and NOTHING else reaches on this device (a measured
+    device-copy / triad ceiling beside the vendor peak): pmg_stream_triad -- read two streams of n doubles, write one, 16 bytes
+    per lane, a tile per workgroup -- over the sizes of one colour pass, HIP events on the launch stream."""
+    import torch
+
+    from parmgmc_amd.capi import check, lib
+
+    n = n_doubles - (n_doubles & 1)
+    a = torch.zeros(n, dtype=torch.float64, device="cuda")
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+    c = torch.empty(n, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        check(lib.pmg_stream_triad(n, a.data_ptr(), b.data_ptr(), c.data_ptr(), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        check(lib.pmg_stream_triad(n, a.data_ptr(), b.data_ptr(), c.data_ptr(), st))
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    ok = bool((c[:: max(1, n // 4096)] == 0.5).all().item())
+    return {"achieved": 24.0 * n / us / 1e3, "unit": "GB/s", "avg_launch_us": us, "launches": reps, "checked": ok, "kernel": "stream_triad_kernel: c = a + 0.5 b, 2 x 8 B read + 8 B written per entry, the sizes of one colour pass"}
+
+
 def mgmc_lowrank_secondary(rank: int = 0, world: int = 1, transport=None, share: bool = False, n: int = 257, levels: int = 5, k: int = 3, its: int = 20) -> dict:
     """Secondary line (BASELINE config 5: "low-rank observation update on a 256^3 grid, dense coarse Cholesky on MFMA,
     4 GPUs"): the MGMC chain on A + B S B^T with k ball observations (reference src/obs.c:135-180,
@@ -635,6 +661,13 @@ def main() -> None:
             "finite": finite,
             "clock_settle": res["settle"],
         }
+        if world == 1 and os.environ.get("PMG_BENCH_NO_CEILING") != "1":
+            try:  # measured ceiling of the access mix, beside the vendor peak `frac` is taken against
+                sc = stream_ceiling(N_local // 2)
+                sc["sweep_over_ceiling"] = achieved / sc["achieved"]
+                out["roofline"]["stream_ceiling"] = sc
+            except Exception as e:  # never allowed to cost the headline line
+                out["roofline"]["stream_ceiling"] = {"error": f"{type(e).__name__}: {e}"}
         if halo_check is not None:
             out["halo_check"] = halo_check
         if res.get("ranks"):

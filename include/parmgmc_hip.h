@@ -546,6 +546,12 @@ pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t
    [kz0, kz0+nz_owned) in natural order (a z-slab builds only its own rows); B is column-major with nobs columns. */
 pmg_status pmg_make_observation_mats_dmda(int32_t nx, int32_t ny, int32_t nzg, int32_t kz0, int32_t nz_owned, int32_t nobs, double sigma2, const double *coords, const double *radii, const double *obsvals, double *B_host, double *S_host, double *f_host);
 
+/* Measurement aid, no reference counterpart: ONE launch of c = a + 0.5 b over n doubles (n even, device vectors 16-byte
+   aligned) with the colour sweep's access mix -- two streams read, one written, 16 bytes per lane, a tile per workgroup --
+   and nothing else.  Timed by bench.py beside the sweep: the bandwidth a kernel of that mix reaches on the device at hand,
+   reported next to the 8 TB/s vendor peak the roofline fraction is taken against. */
+pmg_status pmg_stream_triad(int64_t n, const double *a_dev, const double *b_dev, double *c_dev, void *stream);
+
 /* ---- chain diagnostics (host arrays, host arithmetic -- as in the reference) ---------------------------------- */
 /* Autocorrelation (src/iact.c:17-47): acf[0..n) of the scalar series x[0..n) via a zero-padded FFT */
 pmg_status pmg_autocorrelation(int64_t n, const double *x_host, double *acf_host);

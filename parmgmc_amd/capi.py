@@ -195,6 +195,7 @@ _sig = {
     "pmg_mat_create_dmda": (_int, [_i32, _i32, _i32, _dbl, C.POINTER(_vp)]),
     "pmg_make_observation_mats_dmda": (_int, [_i32, _i32, _i32, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmg_autocorrelation": (_int, [C.c_int64, _vp, _vp]),
+    "pmg_stream_triad": (_int, [_i64, _vp, _vp, _vp, _vp]),
     "pmg_iact": (_int, [C.c_int64, _vp, C.POINTER(_dbl), _vp, C.POINTER(_int)]),
     "pmg_estimate_covariance_errors": (_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "pmg_pc_woodbury_set_solver": (_int, [_vp, _vp]),

@@ -139,9 +139,29 @@ __global__ __launch_bounds__(256) void fill_zero_kernel(double *__restrict__ p, 
   if (i == 0 && (n & 1)) p[n - 1] = 0.0;
 }
 
+// c = a + 0.5 b with the sweep kernel's access shape: 16 bytes per lane, one tile of 256 lanes per block, blocks in memory
+// order -- the access mix of one colour pass (read two streams, write one), nothing else.  What this runs at is the ceiling a
+// kernel of that mix can reach on the device it is measured on ("a measured device-copy/triad ceiling").
+__global__ __launch_bounds__(256) void stream_triad_kernel(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ c, int64_t n2)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n2) return;
+  const d2z x = reinterpret_cast<const d2z *>(a)[i], y = reinterpret_cast<const d2z *>(b)[i];
+  reinterpret_cast<d2z *>(c)[i] = d2z{x.x + 0.5 * y.x, x.y + 0.5 * y.y};
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
+
+// n even, pointers 16-byte aligned
+extern "C" int pmgk_stream_triad(int64_t n, const double *a, const double *b, double *c, void *stream)
+{
+  if (n <= 0) return 0;
+  const int64_t n2 = n / 2;
+  hipLaunchKernelGGL(stream_triad_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, n2);
+  return launch_status();
+}
 
 // p must be 16-byte aligned (device allocations are)
 extern "C" int pmgk_fill_zero(double *p, int64_t n, void *stream)

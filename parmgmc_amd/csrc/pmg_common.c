@@ -55,6 +55,17 @@ pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t
   return PMG_SUCCESS;
 }
 
+/* measurement aid: one launch of c = a + 0.5 b over n doubles with the colour sweep's access mix (include/parmgmc_hip.h) */
+pmg_status pmg_stream_triad(int64_t n, const double *a_dev, const double *b_dev, double *c_dev, void *stream)
+{
+  PMG_CHECK(n >= 0 && (n & 1) == 0, PMG_ERR_ARG_OUTOFRANGE, "an even, non-negative length expected, got %lld", (long long)n);
+  PMG_CHECK(n < ((int64_t)1 << 40), PMG_ERR_ARG_OUTOFRANGE, "length %lld too large for one launch", (long long)n);
+  PMG_CHECK((a_dev && b_dev && c_dev) || n == 0, PMG_ERR_ARG_NULL, "null vector");
+  PMG_CHECK(((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) % 16 == 0, PMG_ERR_ARG_WRONG, "16-byte aligned device vectors expected");
+  PMG_KERNEL(pmgk_stream_triad(n, a_dev, b_dev, c_dev, stream));
+  return PMG_SUCCESS;
+}
+
 /* Index arrays of the caller's PetscInt width (reference include/parmgmc/parmgmc.h:18-24 builds against 32- and 64-bit
    PetscInt; the arrays come from MatSeqAIJGetCSRAndMemType, src/mc_sor.c:250).  The library's own index type is 32-bit
    (an MI355X holds far fewer than 2^31 rows of an AIJ matrix per device): width 32 borrows the arrays, width 64 makes

@@ -160,6 +160,7 @@ int pmgk_lrc_btx_axpy_small(int64_t ns1, int k, const double *M1, const int64_t 
 int pmgk_axpy(int64_t n, double alpha, const double *x, double *y, void *stream);
 /* out[c] = sum over r = 0..nrows-1 (in that order) of in[r*count + c] */
 int pmgk_fill_zero(double *p, int64_t n, void *stream); /* p 16-byte aligned */
+int pmgk_stream_triad(int64_t n, const double *a, const double *b, double *c, void *stream); /* n even, 16-byte aligned */
 int pmgk_sum_rows(int nrows, int count, const double *in, double *out, void *stream);
 /* exchange in two launches: push = copy segments (src -> dst, dst in the neighbours' slots) then raise flag[q] to
    value[q] from the last block; pull = wait for flag[q] >= value[q], then copy segments out of my slots */

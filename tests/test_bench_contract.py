@@ -68,6 +68,8 @@ def test_bench_line_carries_the_contract_fields():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 12 * 64 ** 3
+    sc = rf["stream_ceiling"]  # the measured ceiling of the access mix beside the vendor peak
+    assert sc["unit"] == "GB/s" and sc["checked"] is True and 0 < sc["achieved"] < rf["peak"] and abs(sc["sweep_over_ceiling"] - rf["achieved"] / sc["achieved"]) < 1e-12
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "samples/s"
     assert d["finite"] is True and d["clock_settle"]["settle_launches"] > 0
