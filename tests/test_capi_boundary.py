@@ -58,6 +58,10 @@ def test_argument_errors():
     assert lib.pmg_grid_create(4, 4, 4, 0, 4, 1.0, None) == 85
     assert lib.pmg_grid_set_omega(None, 1.0) == 85
     assert lib.pmg_mcsor_setup(None) == 85
+    assert lib.pmg_stream_triad(7, None, None, None, None) == 63  # odd length
+    assert lib.pmg_stream_triad(8, None, None, None, None) == 85
+    assert lib.pmg_stream_triad(8, 16, 32, 40, None) == 62  # 8-byte aligned only (checked before anything is launched)
+    assert lib.pmg_stream_triad(0, None, None, None, None) == 0
 
 
 def test_grid_coloring_is_bit_exact_red_black():
