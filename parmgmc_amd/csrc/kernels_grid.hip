@@ -267,7 +267,7 @@ __device__ __forceinline__ void grid_thread_position(int nbx, int bandw, int ty,
 // nearly empty wavefront per line.  Same arithmetic per point and noise addressed by grid position, so the mapping does
 // not change the results.
 template <bool NOISY, bool OMEGA1, bool HALO, bool PACKED, bool TAIL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int nby, int bandw, int kbegin, int kstride, int kcount, int tmain, int tailw, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grid_color_sweep_kernel(pmgk_grid_layout L, pmgk_grid_op op, int c, int nbx, int zmain, int bandw, int kbegin, int kstride, int kcount, int tmain, int tailw, pmgk_grid_halo halo, const double *__restrict__ b_own, const double *__restrict__ y_other, double *__restrict__ y_own)
 {
   // blockDim.x == 64: a wavefront is one grid line, so everything that depends on (line, plane) only is
   // wave-uniform; readfirstlane tells the compiler, which then keeps the boundary logic on the scalar unit
@@ -283,8 +283,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grid
     tab_entry  = {e.x, e.y};
   }
   int                         t, j;
-  if (TAIL && (int)blockIdx.z >= kcount) {
-    const int tb  = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * ((int)blockIdx.z - kcount));
+  const int                   zsplit = zmain > 0 ? zmain : kcount; // z layers of main blocks; the tail blocks follow
+  if (TAIL && (int)blockIdx.z >= zsplit) {
+    const int tb  = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * ((int)blockIdx.z - zsplit));
     // On the multigrid sizes nx = 4 tmain + 1 the one tail thread of a line owns the point i = nx - 1 alone, and that point
     // has this colour only on the lines with (c + j + k) even: the tails of those lines are collected (every lane of a tail
     // block busy) instead of one thread per line, half of which would leave at once.  Measured on one box against the
@@ -310,6 +311,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grid
   grid_thread_position<PACKED>(nbx, bandw, ty, t, j);
 
   int k = kbegin + (int)blockIdx.z * kstride;
+  if (!HALO && !PACKED && zmain > 0) {
+    // FLAT (round 4): the wavefronts of an XCD walk the (plane, line) pairs of its band without gaps instead of a rectangle of
+    // line tiles per plane.  513 lines are eight bands of 65 = sixteen workgroups of four lines and a seventeenth with ONE: three
+    // wavefronts per band and plane that leave at once but had to be launched (4.4 % of the launches, 8.3 % at 257 lines) --
+    // measured 2.7 % of the sweep at ny = 520, more at 257 (tools/oddbench.py).  A wavefront's plane and line are wave-uniform as
+    // before; the four wavefronts of a workgroup share nothing, so a workgroup may straddle two planes.
+    const int first = (int)(blockIdx.x & 7u) * bandw, nl = min(bandw, L.ny - first);
+    const int w     = ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z) * 4 + ty;
+    if (nl <= 0) return;
+    const int kz = w / nl;
+    if (kz >= kcount) return; // whole wavefront (the last z layers of the shorter bands)
+    t = (int)(blockIdx.x >> 3) * 64 + (int)threadIdx.x;
+    j = first + (w - kz * nl);
+    k = kbegin + kz * kstride;
+  }
   if (HALO && halo.full) { // face planes first: they carry the halo traffic
     const int z = (int)blockIdx.z;
     k           = z == 0 ? 0 : (z == 1 ? L.nz - 1 : z - 1);
@@ -717,18 +733,20 @@ static inline bool grid_use_packed(const pmgk_grid_layout *L)
 // how one plane's threads are dealt to the wavefronts
 struct grid_mapping {
   bool packed, tail;
-  int  nbx, nby, bandw, tmain, tailw, ztail;
+  int  nbx, nby, bandw, tmain, tailw, ztail, zmain;
   dim3 grid;
 };
 
-static grid_mapping grid_choose_mapping(const pmgk_grid_layout *L, int kcount, bool allow_tail)
+static grid_mapping grid_choose_mapping(const pmgk_grid_layout *L, int kcount, bool allow_tail, bool allow_flat = false)
 {
-  static int banded_env = -1, tail_env = -1;
+  static int banded_env = -1, tail_env = -1, flat_env = -1;
   if (banded_env < 0) {
     const char *e = getenv("PMG_GRID_BANDED");
     banded_env    = e ? atoi(e) : 1;
     e             = getenv("PMG_GRID_TAIL");
     tail_env      = e ? atoi(e) : 1;
+    e             = getenv("PMG_GRID_FLAT");
+    flat_env      = e ? atoi(e) : 1;
   }
   grid_mapping M;
   const int    tpl = L->sx / 2, tplE = grid_threads_per_line(L);
@@ -742,14 +760,18 @@ static grid_mapping grid_choose_mapping(const pmgk_grid_layout *L, int kcount, b
   // XCD-banded dispatch order needs enough line tiles to give every XCD a band
   M.bandw = (!M.packed && banded_env && M.nby >= 16) ? (L->ny + 7) / 8 : 0; // lines per XCD band
   M.ztail = 0;
+  M.zmain = 0;
   if (M.packed) M.grid = dim3((unsigned)(((int64_t)L->ny * tplE + 255) / 256), 1, kcount);
   else {
     const unsigned gx = M.bandw > 0 ? 8 * M.nbx : M.nbx, gy = M.bandw > 0 ? (M.bandw + 3) / 4 : M.nby;
+    // bands that are not whole line tiles, or a short last band: the (plane, line) pairs of a band in one run (see the kernel)
+    if (allow_flat && flat_env && M.bandw > 0 && ((M.bandw & 3) || 8 * M.bandw != L->ny)) M.zmain = (int)(((int64_t)M.bandw * kcount + 4 * gy - 1) / (4 * gy));
+    const int zlayers = M.zmain > 0 ? M.zmain : kcount;
     if (M.tail) {
       const int64_t nblocks = (int64_t)kcount * (((int64_t)L->ny * M.tailw + 255) / 256);
       M.ztail               = (int)((nblocks + (int64_t)gx * gy - 1) / ((int64_t)gx * gy));
     }
-    M.grid = dim3(gx, gy, kcount + M.ztail);
+    M.grid = dim3(gx, gy, zlayers + M.ztail);
   }
   if (!M.tail) M.tmain = M.tailw = 0;
   return M;
@@ -758,15 +780,15 @@ static grid_mapping grid_choose_mapping(const pmgk_grid_layout *L, int kcount, b
 template <bool NOISY, bool OMEGA1, bool HALO>
 static void launch_sweep(const grid_mapping &M, dim3 block, hipStream_t s, const pmgk_grid_layout &L, const pmgk_grid_op &op, int color, int kbegin, int kstride, int kcount, const pmgk_grid_halo &h, const double *bo, const double *yo, double *ys)
 {
-  if (M.packed) hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, true, false>), M.grid, block, 0, s, L, op, color, M.nbx, M.nby, M.bandw, kbegin, kstride, kcount, 0, 0, h, bo, yo, ys);
-  else if (!HALO && M.tail) hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, false, false, true>), M.grid, block, 0, s, L, op, color, M.nbx, M.nby, M.bandw, kbegin, kstride, kcount, M.tmain, M.tailw, h, bo, yo, ys);
-  else hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, false, false>), M.grid, block, 0, s, L, op, color, M.nbx, M.nby, M.bandw, kbegin, kstride, kcount, 0, 0, h, bo, yo, ys);
+  if (M.packed) hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, true, false>), M.grid, block, 0, s, L, op, color, M.nbx, 0, M.bandw, kbegin, kstride, kcount, 0, 0, h, bo, yo, ys);
+  else if (!HALO && M.tail) hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, false, false, true>), M.grid, block, 0, s, L, op, color, M.nbx, M.zmain, M.bandw, kbegin, kstride, kcount, M.tmain, M.tailw, h, bo, yo, ys);
+  else hipLaunchKernelGGL((grid_color_sweep_kernel<NOISY, OMEGA1, HALO, false, false>), M.grid, block, 0, s, L, op, color, M.nbx, HALO ? 0 : M.zmain, M.bandw, kbegin, kstride, kcount, 0, 0, h, bo, yo, ys);
 }
 
 extern "C" int pmgk_grid_color_sweep(const pmgk_grid_layout *L, const pmgk_grid_op *op, int color, int kbegin, int kcount, int kstride, const pmgk_grid_halo *halo, const double *b, double *y, void *stream)
 {
   if (kcount <= 0) return 0;
-  const grid_mapping M = grid_choose_mapping(L, kcount, !halo);
+  const grid_mapping M = grid_choose_mapping(L, kcount, !halo, !halo);
   const dim3         block(64, 4, 1);
   hipStream_t   s  = (hipStream_t)stream;
   const double *bo = b + (int64_t)color * L->cs, *yo = y + (int64_t)(1 - color) * L->cs;
