@@ -317,7 +317,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void grid
     // wavefronts per band and plane that leave at once but had to be launched (4.4 % of the launches, 8.3 % at 257 lines) --
     // measured 2.7 % of the sweep at ny = 520, more at 257 (tools/oddbench.py).  A wavefront's plane and line are wave-uniform as
     // before; the four wavefronts of a workgroup share nothing, so a workgroup may straddle two planes.
-    const int first = (int)(blockIdx.x & 7u) * bandw, nl = min(bandw, L.ny - first);
+    // bandw = floor(ny / 8) lines per band here, the ny - 8 bandw < 8 lines left over go one each to the LAST bands: the first
+    // bands start on whole multiples of bandw lines (measured: -1 % against eight bands of ceil(ny / 8) with a short last one)
+    const int xcd = (int)(blockIdx.x & 7u), extra = max(xcd - (8 - (L.ny - 8 * bandw)), 0);
+    const int first = xcd * bandw + extra, nl = bandw + (xcd >= 8 - (L.ny - 8 * bandw) ? 1 : 0);
     const int w     = ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z) * 4 + ty;
     if (nl <= 0) return;
     const int kz = w / nl;
@@ -765,7 +768,11 @@ static grid_mapping grid_choose_mapping(const pmgk_grid_layout *L, int kcount, b
   else {
     const unsigned gx = M.bandw > 0 ? 8 * M.nbx : M.nbx, gy = M.bandw > 0 ? (M.bandw + 3) / 4 : M.nby;
     // bands that are not whole line tiles, or a short last band: the (plane, line) pairs of a band in one run (see the kernel)
-    if (allow_flat && flat_env && M.bandw > 0 && ((M.bandw & 3) || 8 * M.bandw != L->ny)) M.zmain = (int)(((int64_t)M.bandw * kcount + 4 * gy - 1) / (4 * gy));
+    if (allow_flat && flat_env && M.bandw > 0 && ((M.bandw & 3) || 8 * M.bandw != L->ny)) {
+      M.bandw           = L->ny / 8; // floor: the lines left over go one each to the last bands (see the kernel)
+      const int maxband = M.bandw + (L->ny > 8 * M.bandw ? 1 : 0);
+      M.zmain           = (int)(((int64_t)maxband * kcount + 4 * gy - 1) / (4 * gy));
+    }
     const int zlayers = M.zmain > 0 ? M.zmain : kcount;
     if (M.tail) {
       const int64_t nblocks = (int64_t)kcount * (((int64_t)L->ny * M.tailw + 255) / 256);
