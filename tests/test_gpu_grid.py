@@ -240,6 +240,42 @@ def test_plane_range_sweeps_compose_to_the_full_sweep():
     assert e.value.code == 63
 
 
+@pytest.mark.parametrize("ny", list(range(61, 73)) + [129, 257])
+def test_xcd_bands_of_any_remainder_sweep_every_line_once(ny):
+    """round 4: with >= 61 lines the single-device sweep deals the lines to eight XCD bands of floor(ny/8) (+1 for the last
+    ny mod 8 bands) and lets the wavefronts of a band walk its (plane, line) pairs without gaps (kernels_grid.hip, `zmain`).
+    Every remainder 0..7, an x tail (nx = 2^k+1 at ny = 129) and a plane range: deterministic sweeps bit for bit against the
+    reference loop, the noisy chain against the oracle, and boundary planes + interior == the full pass."""
+    from parmgmc_amd import GridMCSOR
+
+    nx, nz, kappa = (257 if ny == 129 else 12), 5, 2.0
+    A = O.shifted_laplace(nx, ny, nz, kappa)
+    col = O.coloring_redblack(nx, ny, nz)
+    rng = np.random.default_rng(ny)
+    b, y = rng.standard_normal(A.n), rng.standard_normal(A.n)
+    g = GridMCSOR(nx, ny, nz, kappa)
+    for om in (1.0, 1.3):
+        g.set_omega(om)
+        for t in SWEEPS.values():
+            g.set_sweep_type(t)
+            yd = dev(y)
+            g.apply(dev(b), yd)
+            assert np.array_equal(host(yd), O.mcsor_apply(A, col, b, y, om, t)), (ny, om, t)
+    g.set_omega(1.0)
+    g.set_sweep_type(O.SOR_FORWARD)
+    yd = dev(y)
+    g.sample(dev(b), yd, 2, seed=5, counter0=0)
+    want = O.gibbs_samples(A, col, b, y, 2, lambda d: O.noise_grid(nx, ny, nz, 5, d), 1.0, O.SOR_FORWARD, True)
+    assert np.abs(host(yd) - want).max() < 1e-13 * np.abs(want).max(), ny
+    bc = g.to_cvec(dev(b))
+    y1, y2 = g.to_cvec(dev(y)), g.to_cvec(dev(y))
+    for c in (0, 1):
+        g.sweep_color_cvec(c, bc, y1, True, True, 7, 1)
+        for k0, nk in ((0, 1), (nz - 1, 1), (1, nz - 2)):
+            g.sweep_color_planes_cvec(c, k0, nk, bc, y2, True, True, 7, 1)
+    assert np.array_equal(host(y1), host(y2))
+
+
 @pytest.mark.parametrize("grid", [(6, 5, 4, 2.0), (70, 3, 2, 1.0), (64, 6, 5, 10.0)] + TAIL_GRIDS)
 def test_residual_of_both_colours_matches_csr_product(grid):
     """r = b - A y (PCMG's residual, src/pc_gamgmc.c:253-254) from the one-launch kernel that handles both colours:
