@@ -272,12 +272,6 @@ __global__ __launch_bounds__(256) void lrc_scatter_rows_kernel(int64_t ns, const
   if (q < ns) v[rows[q]] = save[q];
 }
 
-__global__ void lrc_mul_kernel(int k, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
-{
-  const int c = threadIdx.x;
-  if (c < k) out[c] = a[c] * b[c];
-}
-
 // ---- round 4: the per-sweep chain of the row-compact form in four launches instead of seven -------------------------------
 // (profiles/r03_cycles_summary.json: at 257^3, k = 3 the low-rank V-cycle sample was 101 launches, 69 of them these small
 // kernels at their launch floor -- +57 % time for three columns on 2 % of the rows).  What was also built and REMOVED: the
@@ -327,7 +321,7 @@ __global__ __launch_bounds__(256) void lrc_axpy_restore_rows_kernel(int64_t ns, 
   w[r]            = save[q];
 }
 
-// fill_normal_rows_kernel + lrc_mul_kernel + lrc_axpy_rows_kernel(save) in one launch: EVERY block draws the k normals of
+// fill_normal_rows_kernel<true> (draw and scale by sqrt(S)) + lrc_axpy_rows_kernel(save) in one launch: EVERY block draws the k normals of
 // the row stream (seed, sweep) itself -- counter-based: the same numbers in every block -- scales them by sqrt(S) and adds
 // B eta to the support rows of b, keeping the old entries.  Same draws (pair c >> 1, branch c & 1), same roundings.
 __global__ __launch_bounds__(256) void lrc_rhs_rows_kernel(int64_t ns, int k, const double *__restrict__ Mc, const int64_t *__restrict__ rows, const double *__restrict__ sqrtS, uint32_t key0, uint32_t key1, uint64_t sweep, double *__restrict__ b, double *__restrict__ save)
@@ -438,12 +432,6 @@ extern "C" int pmgk_lrc_gemm_small(int64_t n, int k, const double *Cm, int64_t l
 {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(lrc_gemm_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, k, Cm, ld, Sb, Bb);
-  return launch_status();
-}
-
-extern "C" int pmgk_lrc_mul(int k, const double *a, const double *b, double *out, void *stream)
-{
-  hipLaunchKernelGGL(lrc_mul_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, a, b, out);
   return launch_status();
 }
 

@@ -143,7 +143,6 @@ int pmgk_lrc_rows_nblocks(int64_t ns);
 int pmgk_lrc_btx(int64_t n, int k, const double *M, int64_t ld, const double *y, double *partial, const double *scale, double *out, void *stream);
 int pmgk_lrc_axpy_cols(int64_t n, int k, const double *M, int64_t ld, const double *coef, double sign, const double *in, double *out, void *stream);
 int pmgk_lrc_gemm_small(int64_t n, int k, const double *Cm, int64_t ld, const double *Sb, double *Bb, void *stream);
-int pmgk_lrc_mul(int k, const double *a, const double *b, double *out, void *stream);
 /* row-compact form (support rows only): Mc is ns x k column-major, rows[q] the position of compact row q in the vectors */
 int pmgk_lrc_mark_rows(int64_t n, int k, const double *A0, const double *A1, const double *A2, int64_t ld, unsigned char *mask, void *stream);
 int pmgk_lrc_gather_rows(int64_t ns, int k, const double *M, int64_t ld, const int64_t *rows, double *Mc, void *stream);
