@@ -12,6 +12,7 @@
 // upper part) so the sum is bit-identical to the reference loop; pad entries have value 0 and point at the
 // row itself.  Vectors handled here are in the permuted numbering.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include "pmg_kernels.h"
 #define PMG_RNG_LITERALS // the transform's constants as literals here: scalar loads in the middle of these kernels' sums cost more than they save (st27 phase +9 % by GRBM_GUI_ACTIVE)
 #define PMG_RNG_TU csr
@@ -196,9 +197,47 @@ __global__ void fill_normal_rows_kernel(int64_t n, uint32_t key0, uint32_t key1,
   if (2 * q + 1 < n) xi[2 * q + 1] = z1;
 }
 
+// Several row streams in ONE launch: block s draws the n normals of the stream (seed[s], sweep[s]) exactly as
+// fill_normal_rows_kernel<true> does -- same counters, same pairing, same product with `scale` -- into xi + s * stride.  The
+// low-rank noise terms of a whole V-cycle sample (one draw of k numbers per directional sweep and level, src/pc_mcgibbs.c:
+// 130-134) are known when the cycle starts; drawn here together, they cost one dependent launch instead of one per sweep.
+struct normal_batch {
+  uint64_t seed[PMGK_NORMAL_BATCH_MAX], sweep[PMGK_NORMAL_BATCH_MAX];
+};
+__global__ void fill_normal_batch_kernel(normal_batch B, int64_t n, const double *__restrict__ scale, double *__restrict__ xi, int64_t stride)
+{
+  __shared__ pmg::LogTabEntry s_logtab[PMG_LOGTAB_SIZE];
+  pmg::load_log_table(s_logtab);
+  __syncthreads();
+  const uint64_t seed = B.seed[blockIdx.x], sweep = B.sweep[blockIdx.x];
+  double        *out  = xi + (int64_t)blockIdx.x * stride;
+  for (int64_t q = threadIdx.x; 2 * q < n; q += blockDim.x) {
+    const double s0 = scale[2 * q], s1 = 2 * q + 1 < n ? scale[2 * q + 1] : 1.;
+    double       z0, z1;
+    pmg::normal_pair((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)sweep, (uint32_t)(sweep >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), s_logtab, z0, z1);
+    out[2 * q] = z0 * s0;
+    if (2 * q + 1 < n) out[2 * q + 1] = z1 * s1;
+  }
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 1; }
 
 } // namespace
+
+// xi[s * stride + i] = scale[i] * z_i(seed[s], sweep[s]), i < n, for s < nstreams <= PMGK_NORMAL_BATCH_MAX (host arrays of seeds and sweeps)
+extern "C" int pmgk_fill_normal_batch(int nstreams, int64_t n, const uint64_t *seed, const uint64_t *sweep, const double *scale, double *xi, int64_t stride, void *stream)
+{
+  if (nstreams <= 0 || n <= 0) return 0;
+  if (nstreams > PMGK_NORMAL_BATCH_MAX) return 1;
+  normal_batch B;
+  memset(&B, 0, sizeof B);
+  for (int s = 0; s < nstreams; ++s) {
+    B.seed[s]  = seed[s];
+    B.sweep[s] = sweep[s];
+  }
+  hipLaunchKernelGGL(fill_normal_batch_kernel, dim3(nstreams), dim3(64), 0, (hipStream_t)stream, B, n, scale, xi, stride);
+  return launch_status();
+}
 
 extern "C" int pmgk_sell_color_sweep(const pmgk_sell *S, int slice0, int nsl, double omega, int noisy, uint64_t seed, uint64_t sweep, const double *b, double *y, void *stream)
 {

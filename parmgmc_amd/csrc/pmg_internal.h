@@ -60,6 +60,10 @@ pmg_status pmg_lrc_rhs_done(pmg_lrc l, void *stream); /* after the sweep that us
 pmg_status pmg_lrc_post(pmg_lrc l, int dir, double *y_lay, void *stream);
 pmg_status pmg_lrc_residual_sub(pmg_lrc l, const double *x_lay, double *r_lay, void *stream);
 pmg_status pmg_lrc_residual_sub_restricted(pmg_lrc l_fine, pmg_lrc l_coarse, const double *x_fine_lay, double *b_coarse_lay, void *stream);
+void       pmg_lrc_preset_eta(pmg_lrc l, uint64_t seed, uint64_t counter0, int n, const double *eta_dev, int64_t stride); /* noise terms drawn ahead */
+uint64_t      pmg_lrc_noise_seed(uint64_t seed);
+const double *pmg_lrc_sqrtS(pmg_lrc l); /* device, k entries */
+int           pmg_lrc_rank(pmg_lrc l);
 void       pmg_lrc_expect_residual(pmg_lrc l, int on); /* the sweeps that follow are in front of a residual of the same vector */
 int        pmg_lrc_is_local(pmg_lrc l);
 void       pmg_lrc_get_sizes(pmg_lrc l, int32_t *k, int64_t *ns, int *dense); /* ns = 0: none of B's support on this rank */

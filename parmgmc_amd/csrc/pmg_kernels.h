@@ -184,6 +184,8 @@ int pmgk_xch_pull(const pmgk_xch_args *a, unsigned *err, void *stream);
 int pmgk_gather_idx(int64_t n, const int32_t *idx, const double *src, double *dst, void *stream);
 int pmgk_scatter_idx(int64_t n, const int32_t *src_idx, const int32_t *dst_idx, const double *src, double *dst, void *stream);
 int pmgk_fill_normal_rows(int64_t n, uint64_t seed, uint64_t sweep, double *xi, void *stream);
+#define PMGK_NORMAL_BATCH_MAX 64
+int pmgk_fill_normal_batch(int nstreams, int64_t n, const uint64_t *seed, const uint64_t *sweep, const double *scale, double *xi, int64_t stride, void *stream); /* host arrays of seeds / sweeps */
 int pmgk_fill_normal_rows_scaled(int64_t n, uint64_t seed, uint64_t sweep, const double *scale, double *xi, void *stream); /* xi = scale o z */
 
 #ifdef __cplusplus

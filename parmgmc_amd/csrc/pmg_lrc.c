@@ -43,6 +43,11 @@ struct pmg_lrc_s {
   double       *partial2;
   const double *bty_vec; /* the vector partial2 belongs to, NULL = none */
   int           want_bty, bty_in_post; /* PMG_LRC_BTY=1 (not the default: no gain measured) */
+  /* noise terms drawn ahead (pmg_lrc_preset_eta): pre_eta + i * pre_stride = sqrt(S) o eta(pre_seed, pre_ctr0 + i), i < pre_n */
+  const double *pre_eta;
+  uint64_t      pre_seed, pre_ctr0;
+  int           pre_n;
+  int64_t       pre_stride;
   int      reduce_in_axpy; /* the partial sums of B^T y are added by the update kernel that consumes them (default); PMG_LRC_REDUCE=0: lrc_reduce_kernel */
   int      restore_in_btx; /* the saved right-hand side entries go back in the B^T y pass of the repair (default); PMG_LRC_RESTORE=0: a kernel of their own */
   int      empty;            /* this rank's rows do not meet the support of B at all (row-distributed operator) */
@@ -283,7 +288,7 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
     *beff = b_lay;
     return PMG_SUCCESS;
   }
-  const uint64_t nseed = seed + 0x632BE59BD9B4E019ull;
+  const uint64_t nseed = pmg_lrc_noise_seed(seed);
   l->bty_vec           = NULL;
   if (l->ns) {
     PMG_CALL(lrc_flush_restore(l, stream));
@@ -295,12 +300,14 @@ pmg_status pmg_lrc_rhs(pmg_lrc l, const double *b_lay, uint64_t seed, uint64_t c
       return PMG_SUCCESS;
     }
   }
-  PMG_KERNEL(pmgk_fill_normal_rows_scaled(l->k, nseed, counter, l->sqrtS, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w), VecPointwiseMult(w, w, sqrtS) */
+  const double *eta = l->eta;
+  if (l->pre_eta && nseed == l->pre_seed && counter >= l->pre_ctr0 && counter - l->pre_ctr0 < (uint64_t)l->pre_n) eta = l->pre_eta + (int64_t)(counter - l->pre_ctr0) * l->pre_stride; /* drawn with the cycle's other noise terms: the same numbers */
+  else PMG_KERNEL(pmgk_fill_normal_rows_scaled(l->k, nseed, counter, l->sqrtS, l->eta, stream)); /* VecSetRandomStandardNormal(pg->w), VecPointwiseMult(w, w, sqrtS) */
   if (l->ns) {
-    PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, l->eta, 1.0, l->b_mod, l->saved, stream)); /* MatMultAdd(B, w, rhs, rhs) */
+    PMG_KERNEL(pmgk_lrc_axpy_rows(l->ns, l->k, l->Bc, l->rows, eta, 1.0, l->b_mod, l->saved, stream)); /* MatMultAdd(B, w, rhs, rhs) */
     return PMG_SUCCESS;
   }
-  PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->B, l->ld, l->eta, 1.0, b_lay, l->beff, stream));  /* MatMultAdd(B, w, rhs, rhs)      */
+  PMG_KERNEL(pmgk_lrc_axpy_cols(l->ld, l->k, l->B, l->ld, eta, 1.0, b_lay, l->beff, stream));  /* MatMultAdd(B, w, rhs, rhs)      */
   *beff = l->beff;
   return PMG_SUCCESS;
 }
@@ -383,6 +390,23 @@ void pmg_lrc_get_sizes(pmg_lrc l, int32_t *k, int64_t *ns, int *dense)
   if (ns) *ns = !l || l->empty ? 0 : (l->ns ? l->ns : l->ld);
   if (dense) *dense = is_dense;
 }
+
+/* The noise terms of the next n directional sweeps are in eta_dev already: eta_dev + i * stride holds the k numbers
+   sqrt(S) o eta the sweep with (seed, counter0 + i) would draw (pmgk_fill_normal_batch with pmg_lrc_noise_seed(seed) and
+   pmg_lrc_sqrtS), written by work queued on the stream the sweeps run on.  pmg_lrc_rhs takes them from there when it is
+   called with a matching (seed, counter) and draws as before otherwise; eta_dev = NULL forgets. */
+void pmg_lrc_preset_eta(pmg_lrc l, uint64_t seed, uint64_t counter0, int n, const double *eta_dev, int64_t stride)
+{
+  if (!l) return;
+  l->pre_eta    = n > 0 ? eta_dev : NULL;
+  l->pre_seed   = pmg_lrc_noise_seed(seed);
+  l->pre_ctr0   = counter0;
+  l->pre_n      = n;
+  l->pre_stride = stride;
+}
+uint64_t      pmg_lrc_noise_seed(uint64_t seed) { return seed + 0x632BE59BD9B4E019ull; } /* the stream of the noise term beside the sweep's own (pmg_lrc_rhs) */
+const double *pmg_lrc_sqrtS(pmg_lrc l) { return l ? l->sqrtS : NULL; }
+int           pmg_lrc_rank(pmg_lrc l) { return l ? l->k : 0; }
 
 /* on: the sweeps that follow are the pre-smoothing of a V-cycle level -- a residual of the same vector comes next (off: whatever
    the last repair left behind is forgotten) */

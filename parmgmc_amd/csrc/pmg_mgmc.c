@@ -90,6 +90,8 @@ struct pmg_mgmc_s {
   /* MATLRC fine operator A + B S B^T (host copies until set-up; src/pc_gamgmc.c:157-196) */
   int32_t   lrc_k;
   double   *lrc_B, *lrc_S;
+  double   *eta_batch; /* device: the low-rank noise terms of one cycle, drawn together (mg_draw_lowrank_noise) */
+  int       eta_batch_mode; /* 0: not asked yet, 1: on, -1: PMG_LRC_BATCH=0 when this sampler ran its first cycle */
   int       own_grid; /* the fine grid operator was created here (not handed in with a slab) */
   /* multi-device: z-slabs of the fine grid, one rank per device (borrowed dist object); cuts[l*(nranks+1) + r] =
      first plane of rank r on level l */
@@ -1694,6 +1696,53 @@ static pmg_status mg_prolong_add(pmg_mgmc h, int l, const double *e_coarse, doub
   return PMG_SUCCESS;
 }
 
+/* the low-rank update a level's sampler applies (held by the level, or by the grid object of a single-device grid level) */
+static pmg_lrc mg_level_lrc(mg_level *Lv) { return Lv->lrc ? Lv->lrc : (Lv->is_grid ? pmg_grid_lrc(Lv->g) : NULL); }
+
+/* The noise terms B (sqrt(S) o eta) of a cycle need one draw of k numbers per directional sweep and level
+   (src/pc_mcgibbs.c:130-134) -- a launch of one wavefront in front of every sweep, ~2 us each on the cycle's critical path
+   (timing probe without them: 0.732 -> 0.715 ms per 257^3 k = 3 sample).  Which (seed, counter) every sweep of the cycle
+   will ask for is known when the cycle starts: they are all drawn by ONE launch here and handed to the levels' updates,
+   which take them when the sweep asks with a matching (seed, counter) and draw themselves otherwise.  Same numbers either
+   way.  Single device only; PMG_LRC_BATCH=0 switches it off. */
+#define MG_ETA_STRIDE 64
+static pmg_status mg_draw_lowrank_noise(pmg_mgmc h, uint64_t seed, const uint64_t *ctr, int on, void *stream)
+{
+  if (!h->eta_batch_mode) {
+    const char *e     = getenv("PMG_LRC_BATCH");
+    h->eta_batch_mode = (e && !atoi(e)) ? -1 : 1;
+  }
+  const int env = h->eta_batch_mode > 0;
+  const int top = h->nlevels - 1, ndir = h->sweep_type == PMG_SOR_SYMMETRIC_SWEEP ? 2 : 1;
+  uint64_t  seeds[PMGK_NORMAL_BATCH_MAX], ctrs[PMGK_NORMAL_BATCH_MAX];
+  int       first[64], count[64], nslots = 0;
+  pmg_lrc   any = NULL;
+  for (int l = 0; l <= top; ++l) {
+    mg_level *Lv = &h->lv[l];
+    pmg_lrc   lr = mg_level_lrc(Lv);
+    first[l] = count[l] = 0;
+    if (!lr) continue;
+    pmg_lrc_preset_eta(lr, 0, 0, 0, NULL, 0); /* forget the last cycle's */
+    if (!on || !env || h->dist || !pmg_lrc_is_local(lr) || pmg_lrc_rank(lr) > MG_ETA_STRIDE) continue;
+    const int n = l >= 1 ? 2 * h->nu * ndir : (h->coarse_type != 0 ? h->coarse_its * ndir : 0); /* pre- and post-smoothing; the sampled coarsest level */
+    if (n <= 0 || nslots + n > PMGK_NORMAL_BATCH_MAX) continue;
+    first[l] = nslots;
+    count[l] = n;
+    for (int i = 0; i < n; ++i) {
+      seeds[nslots + i] = pmg_lrc_noise_seed(level_seed(seed, l));
+      ctrs[nslots + i]  = ctr[l] + (uint64_t)i;
+    }
+    nslots += n;
+    any = lr;
+  }
+  if (!nslots) return PMG_SUCCESS;
+  if (!h->eta_batch) PMG_CALL(pmg_dev_alloc((void **)&h->eta_batch, sizeof(double) * MG_ETA_STRIDE * PMGK_NORMAL_BATCH_MAX));
+  PMG_KERNEL(pmgk_fill_normal_batch(nslots, pmg_lrc_rank(any), seeds, ctrs, pmg_lrc_sqrtS(any), h->eta_batch, MG_ETA_STRIDE, stream)); /* S is the same on every level (src/pc_gamgmc.c:170-176) */
+  for (int l = 0; l <= top; ++l)
+    if (count[l]) pmg_lrc_preset_eta(mg_level_lrc(&h->lv[l]), level_seed(seed, l), ctr[l], count[l], h->eta_batch + (size_t)first[l] * MG_ETA_STRIDE, MG_ETA_STRIDE);
+  return PMG_SUCCESS;
+}
+
 /* one multiplicative V-cycle on lv[top].b -> lv[top].x; x starts at zero on every level below the top, and on the
    top level too unless top_has_guess */
 static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_has_guess, void *stream)
@@ -1703,6 +1752,7 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
   PMG_CHECK(h->nlevels <= 64, PMG_ERR_ARG_OUTOFRANGE, "too many levels");
   for (int l = 0; l <= top; ++l) ctr[l] = sample * MG_DRAWS_PER_SAMPLE;
   for (int l = 0; l <= top; ++l) h->lv[l].x_zeroed = 0; /* (a cycle that ended in an error may have left one set) */
+  if (h->lrc_k > 0) PMG_CALL(mg_draw_lowrank_noise(h, seed, ctr, 1, stream));
   for (int l = top; l >= 1; --l) {
     mg_level *Lv = &h->lv[l], *Cc = &h->lv[l - 1];
     if (l < top || !top_has_guess) {
@@ -1761,9 +1811,10 @@ static pmg_status mg_vcycle(pmg_mgmc h, uint64_t seed, uint64_t sample, int top_
     const int first = h->sweep_type == PMG_SOR_BACKWARD_SWEEP ? 1 : 0;
     const int only  = (h->omega == 1.0 && h->nu >= 1 && !no_skip) ? 1 - first : -1;
     PMG_CALL(mg_prolong_add(h, l, h->lv[l - 1].x, Lv->x, only, stream));
-    pmg_lrc_expect_residual(Lv->lrc ? Lv->lrc : (Lv->is_grid ? pmg_grid_lrc(Lv->g) : NULL), 0); /* no residual behind the post-smoothing */
+    pmg_lrc_expect_residual(mg_level_lrc(Lv), 0); /* no residual behind the post-smoothing */
     PMG_CALL(mg_smooth(h, l, seed, &ctr[l], stream));
   }
+  if (h->lrc_k > 0) PMG_CALL(mg_draw_lowrank_noise(h, seed, ctr, 0, stream)); /* nothing outside this cycle takes its noise terms */
   return PMG_SUCCESS;
 }
 
@@ -2078,6 +2129,7 @@ pmg_status pmg_mgmc_destroy(pmg_mgmc *hp)
   pmg_chol_destroy(&h->chol);
   pmg_dev_free(h->y_lay);
   pmg_dev_free(h->b_lay);
+  pmg_dev_free(h->eta_batch);
   free(h->lrc_B);
   free(h->lrc_S);
   free(h->cuts);

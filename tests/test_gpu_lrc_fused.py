@@ -5,8 +5,8 @@ keep every sum in the order of the kernels they replace, so whole chains must be
 kernels -- the form tests/test_lrc.py and tests/test_gpu_benchsize_lowrank.py pin against the oracle (reference src/mc_sor.c:101-112,
 src/pc_mcgibbs.c:130-140, src/pc_sorgibbs.c:86-101).
 
-Also the two folds that ARE the default since round 4 (the restore of b in the B^T y pass, the partial sums added by the update
-kernel: PMG_LRC_RESTORE=0, PMG_LRC_REDUCE=0 switch them off) and a third that is not (PMG_LRC_BTY=1: the repair in front of a
+Also the three folds that ARE the default since round 4 (the restore of b in the B^T y pass, the partial sums added by the update
+kernel, the noise terms of a whole cycle drawn by one launch: PMG_LRC_RESTORE=0, PMG_LRC_REDUCE=0, PMG_LRC_BATCH=0 switch them off) and a third that is not (PMG_LRC_BTY=1: the repair in front of a
 residual leaves the partial sums of B^T y_new for it; no gain measured), whole V-cycle chains bit for bit."""
 import numpy as np
 import pytest
@@ -101,7 +101,7 @@ def test_fused_chain_on_an_aij_operator(monkeypatch):
 def _vcycle_chain(monkeypatch, env, grid, levels, B, S, b, y0, sweep, its):
     from parmgmc_amd import MGMC
 
-    for key in ("PMG_LRC_FUSED", "PMG_LRC_RESTORE", "PMG_LRC_REDUCE", "PMG_LRC_BTY"):
+    for key in ("PMG_LRC_FUSED", "PMG_LRC_RESTORE", "PMG_LRC_REDUCE", "PMG_LRC_BTY", "PMG_LRC_BATCH"):
         monkeypatch.delenv(key, raising=False)
     for key, val in env.items():
         monkeypatch.setenv(key, val)
@@ -129,8 +129,8 @@ def test_default_folds_equal_their_switched_off_forms_bit_for_bit(monkeypatch, k
     assert 4096 < int((np.abs(B).sum(1) > 0).sum()) < n // 6  # row-compact form, several blocks
     S = rng.uniform(20.0, 90.0, k)
     b, y0 = rng.standard_normal(n), rng.standard_normal(n)
-    want = _vcycle_chain(monkeypatch, {"PMG_LRC_RESTORE": "0", "PMG_LRC_REDUCE": "0"}, grid, levels, B, S, b, y0, sweep, 3)
+    want = _vcycle_chain(monkeypatch, {"PMG_LRC_RESTORE": "0", "PMG_LRC_REDUCE": "0", "PMG_LRC_BATCH": "0"}, grid, levels, B, S, b, y0, sweep, 3)
     assert np.isfinite(want).all()
-    for env in ({}, {"PMG_LRC_BTY": "1"}, {"PMG_LRC_REDUCE": "0"}, {"PMG_LRC_RESTORE": "0"}, {"PMG_LRC_BTY": "1", "PMG_LRC_RESTORE": "0"}):
+    for env in ({}, {"PMG_LRC_BATCH": "0"}, {"PMG_LRC_BTY": "1"}, {"PMG_LRC_REDUCE": "0"}, {"PMG_LRC_RESTORE": "0"}, {"PMG_LRC_BTY": "1", "PMG_LRC_RESTORE": "0"}):
         got = _vcycle_chain(monkeypatch, env, grid, levels, B, S, b, y0, sweep, 3)
         assert np.array_equal(got, want), env
