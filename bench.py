@@ -287,24 +287,27 @@ def unstructured_secondary(refine: int = 5, its: int = 50, larger: bool = True) 
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    mc = MCSOR(A.indptr, A.indices, A.data).setup()
+    from parmgmc_amd import COLORING_ITERATED
+
+    mc = MCSOR(A.indptr, A.indices, A.data, COLORING_ITERATED).setup()  # first-fit + one round of iterated greedy: 5 classes instead of 6 on these matrices
     ncol = mc.get_num_colors()
     ms_sweep = timed(lambda its_, c0: mc.sample(b, y, its_, seed=0xCAFE, counter0=c0, scaled=True), its)
     mg = MGMC.from_hierarchy(ops, ps)
+    mg.set_coloring(COLORING_ITERATED)
     mg.set_smoother(True, 1.0, 1, 1)
     mg.setup()
     y.zero_()
     ms_mg = timed(lambda its_, c0: mg.sample(b, y, its_, seed=0xCAFE, counter0=c0), its)
     alg_mg = mg.algorithmic_bytes()[0]
     sell_note = "12 nnz + 40 N bytes per sweep (SURVEY 8(d): 8 B value + 4 B column per stored entry; rowptr, row index, idiag, b, y read, y write per row) / time per sweep"
-    out = {"workload": f"lshape.msh refined {refine}x: P1 kappa^2 M + K, {n} rows, {nnz} nonzeros; aggregation hierarchy {[len(o[0]) - 1 for o in ops]}", "gibbs_sweep": {"value": 1e3 / ms_sweep, "unit": "samples/s", "ms_per_sample": ms_sweep, "colors": ncol, "roofline": cycle_roofline(12 * nnz + 40 * n, ms_sweep, f"sell_sweep_{n}", 1, sell_note)}, "mgmc": {"value": 1e3 / ms_mg, "unit": "samples/s", "ms_per_sample": ms_mg, "levels": len(ops), "roofline": cycle_roofline(alg_mg, ms_mg, f"mgmc_aij_{n}")}, "host_setup_s": host_s, "finite": bool(torch.isfinite(y).all().item())}
+    out = {"workload": f"lshape.msh refined {refine}x: P1 kappa^2 M + K, {n} rows, {nnz} nonzeros; aggregation hierarchy {[len(o[0]) - 1 for o in ops]}", "gibbs_sweep": {"value": 1e3 / ms_sweep, "unit": "samples/s", "ms_per_sample": ms_sweep, "colors": ncol, "coloring": "first-fit + one round of iterated greedy (PMG_COLORING_ITERATED)", "roofline": cycle_roofline(12 * nnz + 40 * n, ms_sweep, f"sell_sweep_{n}", 1, sell_note)}, "mgmc": {"value": 1e3 / ms_mg, "unit": "samples/s", "ms_per_sample": ms_mg, "levels": len(ops), "roofline": cycle_roofline(alg_mg, ms_mg, f"mgmc_aij_{n}")}, "host_setup_s": host_s, "finite": bool(torch.isfinite(y).all().item())}
     if larger:  # the same sweep one refinement further, where it is no longer bound by the latency of its dependent launches
         del mc, mg
         xy, tris = refine_uniform(xy, tris)
         A2 = assemble_p1(xy, tris, 1.0)
         b2 = torch.ones(A2.shape[0], dtype=torch.float64, device="cuda")
         y2 = torch.zeros(A2.shape[0], dtype=torch.float64, device="cuda")
-        mc2 = MCSOR(A2.indptr, A2.indices, A2.data).setup()
+        mc2 = MCSOR(A2.indptr, A2.indices, A2.data, COLORING_ITERATED).setup()
         ms2 = timed(lambda its_, c0: mc2.sample(b2, y2, its_, seed=0xCAFE, counter0=c0, scaled=True), its)
         out["gibbs_sweep_refined_once_more"] = {"rows": A2.shape[0], "nonzeros": A2.nnz, "ms_per_sample": ms2, "colors": mc2.get_num_colors(), "roofline": cycle_roofline(12 * A2.nnz + 40 * A2.shape[0], ms2, f"sell_sweep_{A2.shape[0]}", 1, sell_note)}
     return out

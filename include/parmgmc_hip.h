@@ -71,6 +71,9 @@ const char *pmg_gpu_arch(void);
 #define PMG_COLORING_GREEDY 0    /* first-fit in natural row order (deterministic; replaces randomised JP)   */
 #define PMG_COLORING_LEXLEVELS 1 /* dependency levels of the natural-order sweep == serial reference / MatSOR */
 #define PMG_COLORING_USER 2      /* caller-supplied ISColoringValue array, validated                          */
+#define PMG_COLORING_ITERATED 3  /* first-fit, then first-fit once more with the classes visited last class first (one round of
+                                    iterated greedy): never more classes than first-fit, 5 instead of 6 on the P1 matrices of
+                                    lshape.msh and their Galerkin levels, i.e. one dependent launch fewer per sweep            */
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* MCSOR on an assembled AIJ matrix: replaces include/parmgmc/mc_sor.h:17-30                               */
@@ -382,6 +385,11 @@ pmg_status pmg_mgmc_set_correction_form(pmg_mgmc mg, int literal);
    restricted form, b_c -= B_{l-1} (S B_l^T x) with B_{l-1} = P^T B_l (src/pc_gamgmc.c:177-178) -- equal up to rounding
    (1e-12 on a whole sample, tests/test_gpu_benchsize_lowrank.py).  Single-device hierarchies: any time; z-slabs: before set-up. */
 pmg_status pmg_mgmc_set_fused_transfers(pmg_mgmc mg, int on);
+/* Colouring rule of the AIJ levels of a hierarchy (pmg_mgmc_create_hierarchy) on one device: PMG_COLORING_GREEDY (default) or
+   PMG_COLORING_ITERATED (one class and one dependent launch fewer per sweep and level on P1 hierarchies); before set-up.  The
+   reference colours every level with PETSc's JP (src/mc_sor.c:383-395): any valid distance-1 colouring is a valid sampler.
+   Row-block levels keep the colouring their plan was built with. */
+pmg_status pmg_mgmc_set_coloring(pmg_mgmc mg, int rule);
 /* MATLRC fine operator A + B S B^T (examples/ex4.c): PCGAMGMC_SetUpHierarchy (src/pc_gamgmc.c:157-196) gives every
    level the operator A_l + B_l S B_l^T, B_{l-1} = P_l^T B_l, for its sampler and its residual; the coarse Cholesky
    sampler factors the explicit sum (src/pc_chols.c:119-153).  B: n_fine x k column-major in the finest level's

@@ -208,6 +208,28 @@ def coloring_greedy(A: CSR) -> np.ndarray:
     return col
 
 
+def coloring_iterated(A: CSR) -> np.ndarray:
+    """First-fit, then first-fit once more with the rows visited class by class, the LAST class first, rows ascending inside
+    a class (one round of iterated greedy; the library's PMG_COLORING_ITERATED).  Never more classes than first-fit."""
+    col0 = coloring_greedy(A)
+    nc0 = int(col0.max()) + 1 if A.n else 0
+    if nc0 <= 2:
+        return col0
+    order = np.lexsort((np.arange(A.n), nc0 - 1 - col0))
+    col = np.full(A.n, -1, np.int32)
+    for r in order:
+        used = set()
+        for k in range(A.rowptr[r], A.rowptr[r + 1]):
+            c = A.colidx[k]
+            if c != r and col[c] >= 0:
+                used.add(int(col[c]))
+        c = 0
+        while c in used:
+            c += 1
+        col[r] = c
+    return col
+
+
 def coloring_lexlevels(A: CSR) -> np.ndarray:
     """Dependency levels of the lexicographic sweep: level(r) = 1 + max level(c), c<r a neighbour.
     A multicolour sweep over these classes in ascending order reproduces plain Gauss-Seidel (the

@@ -7,4 +7,4 @@ There is no CPU fallback: importing :mod:`parmgmc_amd.capi` fails loudly when th
 """
 from .capi import lib, library_path, check, PMGError  # noqa: F401
 from .wrappers import MCSOR, GridMCSOR, CholSampler, MGMC, vec_set_random_standard_normal, autocorrelation, iact, estimate_covariance_errors, make_observation_mats  # noqa: F401
-from .capi import SOR_FORWARD_SWEEP, SOR_BACKWARD_SWEEP, SOR_SYMMETRIC_SWEEP, COLORING_GREEDY, COLORING_LEXLEVELS, COLORING_USER  # noqa: F401
+from .capi import SOR_FORWARD_SWEEP, SOR_BACKWARD_SWEEP, SOR_SYMMETRIC_SWEEP, COLORING_GREEDY, COLORING_LEXLEVELS, COLORING_USER, COLORING_ITERATED  # noqa: F401

@@ -9,7 +9,7 @@ _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
 
 SOR_FORWARD_SWEEP, SOR_BACKWARD_SWEEP, SOR_SYMMETRIC_SWEEP = 1, 2, 3
-COLORING_GREEDY, COLORING_LEXLEVELS, COLORING_USER = 0, 1, 2
+COLORING_GREEDY, COLORING_LEXLEVELS, COLORING_USER, COLORING_ITERATED = 0, 1, 2, 3
 
 
 class PMGError(RuntimeError):
@@ -161,6 +161,7 @@ _sig = {
     "pmg_mgmc_set_lowrank": (_int, [_vp, _i32, _vp, _vp]),
     "pmg_mgmc_set_correction_form": (_int, [_vp, _int]),
     "pmg_mgmc_set_fused_transfers": (_int, [_vp, _int]),
+    "pmg_mgmc_set_coloring": (_int, [_vp, _int]),
     "pmg_mgmc_get_algorithmic_bytes": (_int, [_vp, C.POINTER(_dbl), _vp]),
     "pmg_mgmc_level_lowrank_factors": (_int, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "pmg_mgmc_level_lowrank_post": (_int, [_vp, _i32, _int, _vp, _vp]),

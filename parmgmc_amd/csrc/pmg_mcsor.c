@@ -64,6 +64,46 @@ static pmg_status color_greedy(pmg_mcsor mc)
   return PMG_SUCCESS;
 }
 
+/* First-fit, then first-fit ONCE MORE with the rows visited class by class, the last class first, rows ascending inside a
+   class (one round of Culberson's iterated greedy).  Visiting whole classes one after the other can never need more colours
+   than there are classes, and turning their order round frees the thin last class of a first-fit colouring: the P1 matrices
+   of the refined lshape.msh and their aggregation-Galerkin levels go from 6 classes to 5 (6 033 ... 377 089 rows), i.e. one
+   dependent launch fewer per sweep.  Deterministic, O(nnz), a different but equally valid multicolour sweep. */
+static pmg_status color_iterated(pmg_mcsor mc)
+{
+  PMG_CALL(color_greedy(mc));
+  const int32_t n = mc->n, nc0 = mc->ncolors;
+  if (nc0 <= 2) return PMG_SUCCESS;
+  int32_t *first = (int32_t *)calloc((size_t)nc0 + 1, sizeof(int32_t)), *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1)), *mark = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nc0 + 1));
+  int32_t *newc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  if (!first || !order || !mark || !newc) {
+    free(first), free(order), free(mark), free(newc);
+    PMG_FAIL(PMG_ERR_MEM, "out of host memory");
+  }
+  /* bucket the rows by (reversed) class, ascending inside a class */
+  for (int32_t r = 0; r < n; ++r) ++first[nc0 - 1 - mc->colors[r] + 1];
+  for (int32_t c = 0; c < nc0; ++c) first[c + 1] += first[c];
+  for (int32_t r = 0; r < n; ++r) order[first[nc0 - 1 - mc->colors[r]]++] = r;
+  for (int32_t c = 0; c <= nc0; ++c) mark[c] = -1;
+  for (int32_t r = 0; r < n; ++r) newc[r] = -1;
+  int32_t nc = 0;
+  for (int32_t q = 0; q < n; ++q) {
+    const int32_t r = order[q];
+    for (int32_t k = mc->rowptr[r]; k < mc->rowptr[r + 1]; ++k) {
+      const int32_t c = mc->colidx[k];
+      if (c != r && newc[c] >= 0) mark[newc[c]] = r;
+    }
+    int32_t col = 0;
+    while (mark[col] == r) ++col; /* col < nc0: the rows of one old class are not coupled, so the classes visited so far bound it */
+    newc[r] = col;
+    if (col + 1 > nc) nc = col + 1;
+  }
+  memcpy(mc->colors, newc, sizeof(int32_t) * (size_t)n);
+  mc->ncolors = nc;
+  free(first), free(order), free(mark), free(newc);
+  return PMG_SUCCESS;
+}
+
 /* level(r) = 1 + max level of the neighbours that precede r: sweeping the levels in ascending order is the
    lexicographic Gauss-Seidel sweep of the reference's serial path (one colour, src/mc_sor.c:397-410) */
 static pmg_status color_lexlevels(pmg_mcsor mc)
@@ -144,7 +184,7 @@ pmg_status pmg_mcsor_set_coloring(pmg_mcsor mc, int rule, const int32_t *user_co
 {
   PMG_CHECK(mc, PMG_ERR_ARG_NULL, "null MCSOR");
   PMG_CHECK(!mc->is_setup, PMG_ERR_ARG_WRONGSTATE, "colouring must be chosen before pmg_mcsor_setup");
-  PMG_CHECK(rule == PMG_COLORING_GREEDY || rule == PMG_COLORING_LEXLEVELS || rule == PMG_COLORING_USER, PMG_ERR_ARG_OUTOFRANGE, "unknown colouring rule %d", rule);
+  PMG_CHECK(rule == PMG_COLORING_GREEDY || rule == PMG_COLORING_LEXLEVELS || rule == PMG_COLORING_USER || rule == PMG_COLORING_ITERATED, PMG_ERR_ARG_OUTOFRANGE, "unknown colouring rule %d", rule);
   if (rule == PMG_COLORING_USER) {
     PMG_CHECK(user_colors || mc->n == 0, PMG_ERR_ARG_NULL, "user colouring without colour array");
     free(mc->user_colors);
@@ -241,7 +281,7 @@ pmg_status pmg_mcsor_setup(pmg_mcsor mc)
     free(diagptr);
     PMG_FAIL(PMG_ERR_MEM, "out of host memory");
   }
-  pmg_status st = mc->rule == PMG_COLORING_GREEDY ? color_greedy(mc) : mc->rule == PMG_COLORING_LEXLEVELS ? color_lexlevels(mc) : color_user(mc);
+  pmg_status st = mc->rule == PMG_COLORING_GREEDY ? color_greedy(mc) : mc->rule == PMG_COLORING_ITERATED ? color_iterated(mc) : mc->rule == PMG_COLORING_LEXLEVELS ? color_lexlevels(mc) : color_user(mc);
   if (st) {
     free(diagptr);
     return st;

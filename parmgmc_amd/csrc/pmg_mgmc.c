@@ -90,6 +90,7 @@ struct pmg_mgmc_s {
   /* MATLRC fine operator A + B S B^T (host copies until set-up; src/pc_gamgmc.c:157-196) */
   int32_t   lrc_k;
   double   *lrc_B, *lrc_S;
+  int       aij_coloring; /* rule of the AIJ levels (pmg_mgmc_set_coloring); PMG_COLORING_GREEDY = 0 */
   double   *eta_batch; /* device: the low-rank noise terms of one cycle, drawn together (mg_draw_lowrank_noise) */
   int       eta_batch_mode; /* 0: not asked yet, 1: on, -1: PMG_LRC_BATCH=0 when this sampler ran its first cycle */
   int       own_grid; /* the fine grid operator was created here (not handed in with a slab) */
@@ -603,6 +604,15 @@ pmg_status pmg_mgmc_set_fused_transfers(pmg_mgmc h, int on)
   return PMG_SUCCESS;
 }
 
+pmg_status pmg_mgmc_set_coloring(pmg_mgmc h, int rule)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(!h->is_setup, PMG_ERR_ARG_WRONGSTATE, "the colouring rule must be chosen before set-up");
+  PMG_CHECK(rule == PMG_COLORING_GREEDY || rule == PMG_COLORING_ITERATED, PMG_ERR_ARG_OUTOFRANGE, "colouring rule %d: greedy or iterated expected", rule);
+  h->aij_coloring = rule;
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_mgmc_set_keep_host(pmg_mgmc h, int keep)
 {
   PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
@@ -835,7 +845,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
         free(col);
         PMG_CALL(st);
         PMG_CALL(pmg_mcsor_set_noise_row_offset(Lv->mc, Lv->rb_row0));
-      } else PMG_CALL(pmg_mcsor_set_coloring(Lv->mc, PMG_COLORING_GREEDY, NULL));
+      } else PMG_CALL(pmg_mcsor_set_coloring(Lv->mc, h->aij_coloring, NULL)); /* PMG_COLORING_GREEDY unless pmg_mgmc_set_coloring said otherwise */
       PMG_CALL(pmg_mcsor_set_omega(Lv->mc, h->omega));
       PMG_CALL(pmg_mcsor_set_sweep_type(Lv->mc, h->sweep_type));
       PMG_CALL(pmg_mcsor_setup(Lv->mc));

@@ -482,6 +482,7 @@ static pmg_status gibbs_setfromoptions(pmg_pc pc)
   if (c) {
     if (!strcmp(c, "greedy")) d->coloring = PMG_COLORING_GREEDY;
     else if (!strcmp(c, "lexlevels")) d->coloring = PMG_COLORING_LEXLEVELS;
+    else if (!strcmp(c, "iterated")) d->coloring = PMG_COLORING_ITERATED;
     else PMG_FAIL(PMG_ERR_ARG_WRONG, "unknown colouring %s", c);
   }
   pc->setupcalled = 0;

@@ -313,6 +313,10 @@ class MGMC:
         reference's operation order); True (default): the fused kernel and the restricted low-rank term."""
         check(lib.pmg_mgmc_set_fused_transfers(self._h, int(on)))
 
+    def set_coloring(self, rule: int):
+        """colouring rule of the AIJ levels (capi.COLORING_GREEDY, the default, or capi.COLORING_ITERATED); before setup"""
+        check(lib.pmg_mgmc_set_coloring(self._h, int(rule)))
+
     def set_lowrank(self, B, S):
         """MATLRC fine operator A + B diag(S) B^T, propagated to every level (reference src/pc_gamgmc.c:157-196)."""
         B = np.asfortranarray(B, np.float64)

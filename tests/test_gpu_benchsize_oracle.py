@@ -58,17 +58,18 @@ def lshape_matrix(refine):
     return _cache[refine][2]
 
 
-@pytest.mark.parametrize("refine,rows", [(5, 377089), (6, 1505793)])
-def test_whole_vector_sweeps_at_bench_size(refine, rows):
-    from parmgmc_amd import MCSOR
+@pytest.mark.parametrize("refine,rows,rule", [(5, 377089, "greedy"), (6, 1505793, "greedy"), (5, 377089, "iterated"), (6, 1505793, "iterated")])
+def test_whole_vector_sweeps_at_bench_size(refine, rows, rule):
+    """rule "iterated" (PMG_COLORING_ITERATED, what bench.py sweeps with since round 4): one class fewer than first-fit"""
+    from parmgmc_amd import COLORING_GREEDY, COLORING_ITERATED, MCSOR
 
     As = lshape_matrix(refine)
     assert As.shape[0] == rows
     A = O.CSR.from_scipy(As)
-    mc = MCSOR(As.indptr, As.indices, As.data).setup()
+    mc = MCSOR(As.indptr, As.indices, As.data, COLORING_ITERATED if rule == "iterated" else COLORING_GREEDY).setup()
     col = mc.get_coloring()
-    assert np.array_equal(col, O.coloring_greedy(A)) and O.coloring_is_valid(A, col)  # index maps: bit-exact
-    assert mc.get_num_colors() == col.max() + 1 == 6
+    assert np.array_equal(col, O.coloring_iterated(A) if rule == "iterated" else O.coloring_greedy(A)) and O.coloring_is_valid(A, col)  # index maps: bit-exact
+    assert mc.get_num_colors() == col.max() + 1 == (5 if rule == "iterated" else 6)
     rng = np.random.default_rng(40 + refine)
     b, y = rng.standard_normal(A.n), rng.standard_normal(A.n)
     bd = dev(b)
@@ -93,9 +94,11 @@ def test_whole_vector_sweeps_at_bench_size(refine, rows):
     assert np.abs(host(yd) - want).max() / np.abs(want).max() < 1e-13
 
 
-def test_mgmc_on_the_bench_hierarchy():
-    """bench.py: build_hierarchy(A, coarse_max=2000) -> MGMC.from_hierarchy, set_smoother(True, 1.0, 1, 1)"""
-    from parmgmc_amd import MGMC
+@pytest.mark.parametrize("rule", ["greedy", "iterated"])
+def test_mgmc_on_the_bench_hierarchy(rule):
+    """bench.py: build_hierarchy(A, coarse_max=2000) -> MGMC.from_hierarchy, [set_coloring(COLORING_ITERATED) since round 4,]
+    set_smoother(True, 1.0, 1, 1)"""
+    from parmgmc_amd import COLORING_ITERATED, MGMC
     from parmgmc_amd.unstructured import build_hierarchy
 
     As = lshape_matrix(5)
@@ -104,6 +107,8 @@ def test_mgmc_on_the_bench_hierarchy():
     assert sizes == [1549, 6033, 23809, 94593, 377089]
     nl = len(ops)
     mg = MGMC.from_hierarchy(ops, ps)
+    if rule == "iterated":
+        mg.set_coloring(COLORING_ITERATED)
     mg.set_smoother(True, 1.0, 1, 1)
     mg.setup()
     n = sizes[-1]
@@ -115,7 +120,9 @@ def test_mgmc_on_the_bench_hierarchy():
     Ps = [None] + [sp.csr_matrix((p[2], p[1], p[0]), shape=(sizes[l], sizes[l - 1])) for l, p in enumerate(ps) if p is not None]
     csr = [O.CSR.from_scipy(m) for m in mats]
     lv = [dict(A=mats[l], P=Ps[l]) for l in range(nl)]
-    cols = [O.coloring_greedy(m) for m in csr]
+    cols = [(O.coloring_iterated if rule == "iterated" else O.coloring_greedy)(m) for m in csr]
+    if rule == "iterated":
+        assert [int(c.max()) + 1 for c in cols[1:]] == [5, 5, 5, 5]  # first-fit: 6 on every level
     Lc = O.potrf_lower(csr[0].dense())
     y = y0.copy()
     for s in range(2):

@@ -40,16 +40,18 @@ def cases():
 
 
 @pytest.mark.parametrize("name,A", list(cases()), ids=[c[0] for c in cases()])
-@pytest.mark.parametrize("rule", ["greedy", "lexlevels"])
+@pytest.mark.parametrize("rule", ["greedy", "lexlevels", "iterated"])
 def test_deterministic_sweep_is_bit_exact(name, A, rule):
-    from parmgmc_amd import COLORING_GREEDY, COLORING_LEXLEVELS, MCSOR
+    from parmgmc_amd import COLORING_GREEDY, COLORING_ITERATED, COLORING_LEXLEVELS, MCSOR
 
     rng = np.random.default_rng(2)
     b, y = rng.standard_normal(A.n), rng.standard_normal(A.n)
-    mc = MCSOR(A.rowptr, A.colidx, A.vals, COLORING_GREEDY if rule == "greedy" else COLORING_LEXLEVELS).setup()
+    mc = MCSOR(A.rowptr, A.colidx, A.vals, {"greedy": COLORING_GREEDY, "lexlevels": COLORING_LEXLEVELS, "iterated": COLORING_ITERATED}[rule]).setup()
     col = mc.get_coloring()
     # colouring / index maps bit-exact against the build's stated rules
-    assert np.array_equal(col, O.coloring_greedy(A) if rule == "greedy" else O.coloring_lexlevels(A))
+    assert np.array_equal(col, {"greedy": O.coloring_greedy, "lexlevels": O.coloring_lexlevels, "iterated": O.coloring_iterated}[rule](A))
+    if rule == "iterated":
+        assert col.max() <= O.coloring_greedy(A).max()  # never more classes than first-fit
     assert mc.get_num_colors() == col.max() + 1 and O.coloring_is_valid(A, col)
     for om in (1.0, 1.2):
         mc.set_omega(om)

@@ -56,7 +56,7 @@ def test_stationary_covariance_is_inverse_precision(grid, om, sweep, colors):
 def test_colorings_are_valid_and_deterministic():
     for g in [(9, 9, 1), (6, 5, 4), (2, 2, 2), (3, 1, 1)]:
         A = O.shifted_laplace(*g, 1.0)
-        for col in (O.coloring_redblack(*g), O.coloring_greedy(A), O.coloring_lexlevels(A)):
+        for col in (O.coloring_redblack(*g), O.coloring_greedy(A), O.coloring_lexlevels(A), O.coloring_iterated(A)):
             assert O.coloring_is_valid(A, col)
         assert O.coloring_redblack(*g).max() <= 1
         assert np.array_equal(O.coloring_greedy(A), O.coloring_redblack(*g))  # first-fit on a star stencil is red-black

@@ -15,7 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from parmgmc_amd import MCSOR, MGMC, make_observation_mats  # noqa: E402
+from parmgmc_amd import COLORING_ITERATED, MCSOR, MGMC, make_observation_mats  # noqa: E402
 
 key = sys.argv[1]
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -58,7 +58,7 @@ if key.startswith("mgmc_lowrank_") or (key.startswith("mgmc_") and not key.start
 elif key.startswith("sell_sweep_"):
     rows = int(key.split("_")[2])
     A = lshape({377089: 5, 1505793: 6}[rows])
-    mc = MCSOR(A.indptr, A.indices, A.data).setup()
+    mc = MCSOR(A.indptr, A.indices, A.data, int(os.environ.get('PMG_BENCH_COLORING', COLORING_ITERATED))).setup()  # as bench.py: first-fit + one round of iterated greedy
     b = torch.ones(rows, dtype=torch.float64, device="cuda")
     y = torch.zeros(rows, dtype=torch.float64, device="cuda")
     alg = 12 * A.nnz + 40 * rows
@@ -69,6 +69,7 @@ elif key.startswith("mgmc_aij_"):
     A = lshape(5)
     ops, ps = build_hierarchy(A, coarse_max=2000)
     mg = MGMC.from_hierarchy(ops, ps)
+    mg.set_coloring(int(os.environ.get('PMG_BENCH_COLORING', COLORING_ITERATED)))
     mg.set_smoother(True, 1.0, 1, 1)
     mg.setup()
     b = torch.ones(A.shape[0], dtype=torch.float64, device="cuda")
