@@ -59,7 +59,7 @@ pmg_status pmg_vec_set_random_standard_normal(int64_t n, double *x_dev, uint64_t
 pmg_status pmg_stream_triad(int64_t n, const double *a_dev, const double *b_dev, double *c_dev, void *stream)
 {
   PMG_CHECK(n >= 0 && (n & 1) == 0, PMG_ERR_ARG_OUTOFRANGE, "an even, non-negative length expected, got %lld", (long long)n);
-  PMG_CHECK(n < ((int64_t)1 << 40), PMG_ERR_ARG_OUTOFRANGE, "length %lld too large for one launch", (long long)n);
+  PMG_CHECK(n < ((int64_t)1 << 37), PMG_ERR_ARG_OUTOFRANGE, "length %lld too large for one launch", (long long)n); /* n / 512 workgroups */
   PMG_CHECK((a_dev && b_dev && c_dev) || n == 0, PMG_ERR_ARG_NULL, "null vector");
   PMG_CHECK(((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) % 16 == 0, PMG_ERR_ARG_WRONG, "16-byte aligned device vectors expected");
   PMG_KERNEL(pmgk_stream_triad(n, a_dev, b_dev, c_dev, stream));
