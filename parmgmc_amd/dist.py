@@ -803,7 +803,7 @@ class DistAIJMGMC:
     sweeps, ghost updates, residuals, transfers, coarse solve -- runs in C (pmg_mgmc.c) on the stream; this class only
     slices the matrices and builds the ghost plans (host set-up, collective).  Bit-identical to MGMC.from_hierarchy."""
 
-    def __init__(self, operators, interpolations, rank: int, world: int, group=None, transport=None, starts=None, replicate_below: int = 50000):
+    def __init__(self, operators, interpolations, rank: int, world: int, group=None, transport=None, starts=None, replicate_below: int = 50000, coloring: int = 0):
         import ctypes as C
         import os
 
@@ -832,7 +832,7 @@ class DistAIJMGMC:
         colorings = [None] * L
         for l in range(fold, L):
             rp, ci, v = operators[l]
-            mc = MCSOR(np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(v, np.float64)).setup()
+            mc = MCSOR(np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(v, np.float64), coloring).setup()  # capi.COLORING_GREEDY (0) or COLORING_ITERATED: what MGMC.from_hierarchy + set_coloring(rule) sweeps with on one device
             colorings[l] = (mc.get_coloring(), mc.get_num_colors())
             mc.destroy()
         H = rowblock_hierarchy(operators, interpolations, colorings, rank, world, starts=starts, replicate_below=replicate_below, group=group)
@@ -842,6 +842,7 @@ class DistAIJMGMC:
         self._keep = [H]
         self._h = C.c_void_p()
         check(lib.pmg_mgmc_create_hierarchy(L, C.byref(self._h)))
+        check(lib.pmg_mgmc_set_coloring(self._h, int(coloring)))  # the replicated AIJ levels below the fold
         a0 = sp.csr_matrix((np.asarray(operators[0][2], np.float64), np.asarray(operators[0][1], np.int64), np.asarray(operators[0][0], np.int64)), shape=(n[0], n[0]))
         a0.sort_indices()
         rp0, ci0, v0 = a0.indptr.astype(np.int32), a0.indices.astype(np.int32), np.ascontiguousarray(a0.data)

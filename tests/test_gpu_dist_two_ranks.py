@@ -331,7 +331,7 @@ def _aij_mg_worker(rank, world, port, refine, coarse_max, opts, its, q):
     from parmgmc_amd.dist import DistAIJMGMC
 
     ops, ps = _aij_hierarchy(refine, coarse_max)
-    mg = DistAIJMGMC(ops, ps, rank, world, transport="ipc", replicate_below=opts["replicate_below"])
+    mg = DistAIJMGMC(ops, ps, rank, world, transport="ipc", replicate_below=opts["replicate_below"], coloring=opts.get("coloring", 0))
     mg.set_smoother(opts["scaled"], opts["omega"], opts["sweep"], opts["nu"])
     mg.set_correction_form(opts["literal"])
     n = len(ops[-1][0]) - 1
@@ -364,7 +364,8 @@ def _aij_mg_worker(rank, world, port, refine, coarse_max, opts, its, q):
     (3, 300, 3, {"replicate_below": 2000, "scaled": True, "sweep": 3}),                     # 5 levels: 114, 408, 1549 replicated, 6033 and 23809 by row blocks
     (3, 300, 2, {"replicate_below": 500, "lowrank": True, "scaled": True}),                  # the low-rank block is handed to the replicated levels at the fold
     (2, 300, 2, {"replicate_below": 10 ** 9}),                                                # only the finest level by row blocks
-], ids=["1rank", "2ranks", "3ranks_symmetric_nu2", "4ranks_backward_4levels", "2ranks_literal", "3ranks_lowrank", "2ranks_lowrank_literal", "3ranks_replicated_small_levels", "2ranks_replicated_lowrank", "2ranks_only_finest_distributed"])
+    (3, 300, 2, {"replicate_below": 2000, "scaled": True, "coloring": 3}),                   # PMG_COLORING_ITERATED on row-block and replicated levels (round 4)
+], ids=["1rank", "2ranks", "3ranks_symmetric_nu2", "4ranks_backward_4levels", "2ranks_literal", "3ranks_lowrank", "2ranks_lowrank_literal", "3ranks_replicated_small_levels", "2ranks_replicated_lowrank", "2ranks_only_finest_distributed", "2ranks_iterated_colouring"])
 def test_row_block_distributed_aij_vcycle_reproduces_the_single_device_chain(refine, coarse_max, world, opts):
     """PCGAMGMC on a MATMPIAIJ hierarchy (reference src/pc_gamgmc.c:157-223 over MCSORApply_MPIAIJ, src/mc_sor.c:298-381):
     the aggregation hierarchy of the P1 matrix of the reference's lshape.msh, every level above the coarsest split into
@@ -395,6 +396,7 @@ def test_row_block_distributed_aij_vcycle_reproduces_the_single_device_chain(ref
     rng = np.random.default_rng(5)
     b_all, y_all = rng.standard_normal(n), rng.standard_normal(n)
     one = MGMC.from_hierarchy(ops, ps)
+    one.set_coloring(o.get("coloring", 0))
     one.set_smoother(o["scaled"], o["omega"], o["sweep"], o["nu"])
     one.set_correction_form(o["literal"])
     if o.get("lowrank"):
