@@ -18,7 +18,8 @@
  * One rank: the reference sweeps its rows in ONE colour, i.e. lexicographically (MatCreateISColoring_Seq, src/mc_sor.c:
  * 397-410).  A device sweep needs a valid colouring, so the default here is the library's LEXLEVELS rule -- the dependency
  * levels of the natural order, which reproduce the lexicographic result update for update (include/parmgmc_hip.h) --
- * and -mc_sor_hip_greedy selects the first-fit multicolouring (fewer launches, a different but equally valid sweep).
+ * and -mc_sor_hip_greedy selects the first-fit multicolouring (fewer launches, a different but equally valid sweep),
+ * -mc_sor_hip_iterated first-fit followed by one round of iterated greedy (often one colour fewer still).
  * MCSORGetNumColors / MCSORGetISColoring report the colouring the device actually sweeps (the reference would say 1).
  * Several ranks: first-fit on the global matrix, rank after rank (the reference: PETSc's randomised JP, src/mc_sor.c:383-395).
  *
@@ -32,7 +33,8 @@ typedef struct {
   Mat           A; /* borrowed, like the reference's ctx->A */
   PetscReal     omega;
   MatSORType    type;
-  PetscBool     greedy; /* -mc_sor_hip_greedy */
+  PetscBool     greedy;   /* -mc_sor_hip_greedy */
+  PetscBool     iterated; /* -mc_sor_hip_iterated: first-fit + one round of iterated greedy (PMG_COLORING_ITERATED) */
   pmg_mcsor     mc;
   pmg_distmcsor dm; /* more than one rank */
   pmg_dist      transport;
@@ -55,6 +57,7 @@ PetscErrorCode MCSORCreate(Mat A, MCSOR *m)
   h->type  = SOR_FORWARD_SWEEP;
   PetscCall(PetscOptionsGetReal(NULL, NULL, "-mc_sor_omega", &h->omega, NULL)); /* src/mc_sor.c:638 */
   PetscCall(PetscOptionsGetBool(NULL, NULL, "-mc_sor_hip_greedy", &h->greedy, NULL));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-mc_sor_hip_iterated", &h->iterated, NULL));
   mc->ctx = h;
   *m      = mc;
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -137,7 +140,7 @@ PetscErrorCode MCSORSetUp(MCSOR m)
     h->nowned = n;
     PetscCall(MatSeqAIJGetCSRAndMemType(Aseq, &ia, &ja, &aa, NULL)); /* borrowed host arrays, src/mc_sor.c:250 */
     PMGCall(pmg_mcsor_create_csr_idx((int64_t)n, ia, ja, aa, PMG_IDX_WIDTH, &h->mc));
-    PMGCall(pmg_mcsor_set_coloring(h->mc, h->greedy ? PMG_COLORING_GREEDY : PMG_COLORING_LEXLEVELS, NULL));
+    PMGCall(pmg_mcsor_set_coloring(h->mc, h->iterated ? PMG_COLORING_ITERATED : (h->greedy ? PMG_COLORING_GREEDY : PMG_COLORING_LEXLEVELS), NULL));
     PMGCall(pmg_mcsor_set_omega(h->mc, h->omega));
     PMGCall(pmg_mcsor_set_sweep_type(h->mc, (int)h->type));
     PMGCall(pmg_mcsor_setup(h->mc));

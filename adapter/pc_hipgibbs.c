@@ -37,6 +37,7 @@ typedef struct {
   PetscReal   omega;
   MatSORType  type;
   PetscBool   lexicographic; /* colouring = dependency levels of the natural order: PETSc MatSOR's result, update for update */
+  PetscBool   iterated;      /* one rank: first-fit + one round of iterated greedy (PMG_COLORING_ITERATED): a class fewer on P1 meshes */
   uint64_t    seed, counter;
   HipStageBuf bbuf, ybuf;
   PetscInt    ncolors;
@@ -159,7 +160,7 @@ static PetscErrorCode PCSetUp_HipGibbs(PC pc)
   PetscCall(MatGetSize(A, &n, NULL));
   PetscCall(MatSeqAIJGetCSRAndMemType(A, &ia, &ja, &aa, NULL)); /* borrowed host arrays, as src/mc_sor.c:250 */
   PMGCall(pmg_mcsor_create_csr_idx((int64_t)n, ia, ja, aa, PMG_IDX_WIDTH, &hg->mc));
-  PMGCall(pmg_mcsor_set_coloring(hg->mc, hg->lexicographic ? PMG_COLORING_LEXLEVELS : PMG_COLORING_GREEDY, NULL));
+  PMGCall(pmg_mcsor_set_coloring(hg->mc, hg->lexicographic ? PMG_COLORING_LEXLEVELS : (hg->iterated ? PMG_COLORING_ITERATED : PMG_COLORING_GREEDY), NULL));
   PMGCall(pmg_mcsor_set_omega(hg->mc, hg->scaled ? hg->omega : 1.0));
   PMGCall(pmg_mcsor_set_sweep_type(hg->mc, (int)hg->type));
   if (islrc) { /* A + B S B^T: PrepareRHS_LRC + MCSORPostSOR_LRC (src/pc_mcgibbs.c:130-140, src/mc_sor.c:101-112) */
@@ -278,6 +279,7 @@ static PetscErrorCode PCSetFromOptions_HipGibbs(PC pc, PetscOptionItems_ARG Pets
   /* not in the reference: the order of the device sweep.  Default: greedy multicolouring (few colours = few launches);
      lexicographic = the dependency levels of the natural order, i.e. PETSc MatSOR's result update for update */
   PetscCall(PetscOptionsBool("-pc_hipgibbs_lexicographic", "sweep in the dependency levels of the natural row order (MatSOR's order)", NULL, hg->lexicographic, &hg->lexicographic, NULL));
+  PetscCall(PetscOptionsBool("-pc_hipgibbs_iterated_coloring", "one rank: first-fit colouring followed by one round of iterated greedy (never more colours, often one fewer)", NULL, hg->iterated, &hg->iterated, NULL));
   PetscOptionsHeadEnd();
   if (hg->mc) { /* options changed after set-up: the library applies them lazily like MCSORSetOmega (src/mc_sor.c:412-420) */
     PMGCall(pmg_mcsor_set_omega(hg->mc, hg->scaled ? hg->omega : 1.0));
@@ -293,7 +295,7 @@ static PetscErrorCode PCView_HipGibbs(PC pc, PetscViewer viewer)
   PetscFunctionBeginUser;
   if (hg->scaled) PetscCall(PetscViewerASCIIPrintf(viewer, "Number of colours: %" PetscInt_FMT "\n", hg->ncolors)); /* src/pc_mcgibbs.c:257-266 */
   else PetscCall(PetscViewerASCIIPrintf(viewer, "Sweep type: Forward\n"));                                           /* src/pc_sorgibbs.c:300 */
-  PetscCall(PetscViewerASCIIPrintf(viewer, "Device sweep: libparmgmc_hip %s (%s), %s order, %" PetscInt_FMT " colour launches per sweep\n", pmg_version(), pmg_gpu_arch(), hg->lexicographic ? "lexicographic" : "greedy multicolour", hg->ncolors));
+  PetscCall(PetscViewerASCIIPrintf(viewer, "Device sweep: libparmgmc_hip %s (%s), %s order, %" PetscInt_FMT " colour launches per sweep\n", pmg_version(), pmg_gpu_arch(), hg->lexicographic ? "lexicographic" : (hg->iterated ? "iterated-greedy multicolour" : "greedy multicolour"), hg->ncolors));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
