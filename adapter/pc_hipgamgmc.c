@@ -205,6 +205,11 @@ static PetscErrorCode HipGAMGMCRowBlocks(PC pc, PetscInt levels)
   PetscCall(PetscOptionsGetInt(NULL, prefix, "-pc_gamgmc_hip_replicate_below", &repl, NULL)); /* levels with at most that many rows run redundantly on every rank */
   PetscCall(HipCreateTransport(&pg->hc, NULL, &pg->transport));
   PMGCall(pmg_rbh_create(&pg->hc, (int32_t)levels, (int64_t)repl, &rbh));
+  {
+    PetscBool iterated = PETSC_FALSE; /* first-fit + one round of iterated greedy on every level: one colour (and one ghost update per sweep) fewer on P1 hierarchies */
+    PetscCall(PetscOptionsGetBool(NULL, prefix, "-pc_gamgmc_hip_iterated_coloring", &iterated, NULL));
+    if (iterated) PMGCall(pmg_rbh_set_coloring(rbh, PMG_COLORING_ITERATED));
+  }
   for (PetscInt l = 0; l < levels; ++l) {
     KSP      ksp;
     PC       pcl;
@@ -324,7 +329,14 @@ static PetscErrorCode PCSetUp_HipGAMGMC(PC pc)
       PetscCall(PetscFree(cuts));
       pg->nowned = pg->nlocal = dims[0] * dims[1] * zm;
     } else PetscCall(HipGAMGMCRowBlocks(pc, levels)); /* MATMPIAIJ levels by row blocks */
-  } else PMGCall(pmg_mgmc_create_hierarchy((int32_t)levels, &pg->h));
+  } else {
+    PetscBool   iterated = PETSC_FALSE;
+    const char *pfx;
+    PMGCall(pmg_mgmc_create_hierarchy((int32_t)levels, &pg->h));
+    PetscCall(PCGetOptionsPrefix(pc, &pfx));
+    PetscCall(PetscOptionsGetBool(NULL, pfx, "-pc_gamgmc_hip_iterated_coloring", &iterated, NULL));
+    if (iterated) PMGCall(pmg_mgmc_set_coloring(pg->h, PMG_COLORING_ITERATED));
+  }
   for (PetscInt l = 0; l < levels && size == 1; ++l) {
     KSP             ksp;
     PC              pcl;

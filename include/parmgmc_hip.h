@@ -467,6 +467,9 @@ pmg_status pmg_rowblock_merge_mpiaij(int32_t nloc, int64_t cstart, const void *a
 /* The library's first-fit colouring of the GLOBAL matrix (rows ascending, smallest colour no coloured neighbour carries),
    computed rank after rank: the colouring one process computes.  row_starts[0..nranks] = MatGetOwnershipRanges. */
 pmg_status pmg_rowblock_color_greedy(const pmg_host_comm *comm, const int64_t *row_starts, const int64_t *rowptr, const int64_t *colidx_global, int32_t *colors_owned, int32_t *ncolors);
+/* the same for PMG_COLORING_ITERATED: the first-fit classes revisited last class first, every rank colouring its rows of a class
+   at once, one exchange of the assigned colours per class -- the colouring pmg_mcsor's rule gives one process.  Collective. */
+pmg_status pmg_rowblock_color_iterated(const pmg_host_comm *comm, const int64_t *row_starts, const int64_t *rowptr, const int64_t *colidx_global, int32_t *colors_owned, int32_t *ncolors);
 /* Ghost rows + per-colour ghost-update plan of one row block: MatCreateScatters (src/mc_sor.c:152-214) de-duplicated per
    ghost row and laid out for ONE all-gather per colour.  cols: the global column indices of this rank's rows; extra:
    further rows of other ranks it reads (transfer columns).  Views (pmg_rowblock_plan_get, borrowed): ghosts = sorted global
@@ -502,6 +505,7 @@ pmg_status pmg_rbh_create(const pmg_host_comm *comm, int32_t nlevels, int64_t re
 pmg_status pmg_rbh_set_level_operator(pmg_rbh h, int32_t level, int64_t n_global, int64_t row0, int64_t nloc, const void *rowptr, const void *colidx_global, const double *vals, int idx_width);
 pmg_status pmg_rbh_set_level_interpolation(pmg_rbh h, int32_t level, int64_t nloc_rows, const void *rowptr, const void *colidx_global_coarse, const double *vals, int idx_width);
 pmg_status pmg_rbh_set_level_coloring(pmg_rbh h, int32_t level, int32_t ncolors, const int32_t *colors_owned);
+pmg_status pmg_rbh_set_coloring(pmg_rbh h, int rule); /* PMG_COLORING_GREEDY (default) | PMG_COLORING_ITERATED for the levels without a caller's colouring; before pmg_rbh_build */
 pmg_status pmg_rbh_build(pmg_rbh h);
 pmg_status pmg_rbh_get_info(pmg_rbh h, int32_t *nlevels, int32_t *fold);
 pmg_status pmg_rbh_get_level(pmg_rbh h, int32_t level, pmg_rbh_level_view *view);

@@ -235,6 +235,7 @@ _sig = {
     # row-block set-up in C (pmg_rowblock.c); the pmg_host_comm argument is a pointer to HostComm
     "pmg_rowblock_merge_mpiaij": (_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "pmg_rowblock_color_greedy": (_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
+    "pmg_rowblock_color_iterated": (_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "pmg_rowblock_check_coloring": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "pmg_rowblock_plan_create": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _vp, C.POINTER(_vp)]),
     "pmg_rowblock_plan_get": (_int, [_vp, C.POINTER(_i32)] + [C.POINTER(_vp)] * 7),
@@ -243,6 +244,7 @@ _sig = {
     "pmg_rbh_set_level_operator": (_int, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _int]),
     "pmg_rbh_set_level_interpolation": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _int]),
     "pmg_rbh_set_level_coloring": (_int, [_vp, _i32, _i32, _vp]),
+    "pmg_rbh_set_coloring": (_int, [_vp, _int]),
     "pmg_rbh_build": (_int, [_vp]),
     "pmg_rbh_get_info": (_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "pmg_rbh_get_level": (_int, [_vp, _i32, _vp]),

@@ -487,6 +487,79 @@ pmg_status pmg_rowblock_color_greedy(const pmg_host_comm *comm, const int64_t *r
   return PMG_SUCCESS;
 }
 
+/* PMG_COLORING_ITERATED (pmg_mcsor.c color_iterated) on the GLOBAL matrix: first-fit as above, then first-fit once more with
+   the rows visited class by class, the last class first.  The rows of one first-fit class are not coupled, so every rank colours
+   its rows of the class at the same time; between two classes the ranks exchange what they assigned (one all-gather of the owned
+   colour arrays per class) -- the colouring one process computes, whatever the number of ranks.  Collective. */
+pmg_status pmg_rowblock_color_iterated(const pmg_host_comm *comm, const int64_t *row_starts, const int64_t *rp, const int64_t *ci, int32_t *colors_owned, int32_t *ncolors)
+{
+  PMG_CALL(pmg_rowblock_color_greedy(comm, row_starts, rp, ci, colors_owned, ncolors));
+  const int     np = comm->nranks, me = comm->rank, nc0 = *ncolors;
+  const int64_t r0 = row_starts[me], r1 = row_starts[me + 1], nloc = r1 - r0;
+  if (nc0 <= 2) return PMG_SUCCESS;
+  pmg_status st = PMG_SUCCESS;
+  int64_t    ngh = 0, maxdeg = 0;
+  for (int64_t k = 0; k < rp[nloc]; ++k) ngh += ci[k] < r0 || ci[k] >= r1;
+  for (int64_t i = 0; i < nloc; ++i)
+    if (rp[i + 1] - rp[i] > maxdeg) maxdeg = rp[i + 1] - rp[i];
+  int64_t *gh   = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ngh > 0 ? ngh : 1));
+  int64_t *offs = (int64_t *)malloc(sizeof(int64_t) * (size_t)(np + 1));
+  int32_t *newc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nloc > 0 ? nloc : 1));
+  int32_t *mark = (int32_t *)malloc(sizeof(int32_t) * (size_t)(maxdeg + 2));
+  int32_t *gcol = NULL, *gown = NULL;
+  if (!gh || !offs || !newc || !mark) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+  if (!st) {
+    int64_t q = 0;
+    for (int64_t k = 0; k < rp[nloc]; ++k)
+      if (ci[k] < r0 || ci[k] >= r1) gh[q++] = ci[k];
+    ngh  = sort_unique(gh, ngh);
+    gcol = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ngh > 0 ? ngh : 1));
+    gown = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ngh > 0 ? ngh : 1));
+    if (!gcol || !gown) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+    for (int64_t g = 0, r = 0; g < ngh && !st; ++g) { /* the ghosts are sorted: their owners ascend */
+      while (r + 1 < np && gh[g] >= row_starts[r + 1]) ++r;
+      gown[g] = (int32_t)r;
+      gcol[g] = -1;
+    }
+    for (int64_t i = 0; i < nloc; ++i) newc[i] = -1;
+    for (int64_t i = 0; i <= maxdeg + 1; ++i) mark[i] = -1;
+  }
+  st = hc_agree(comm, st, "preparing the second colouring round");
+  int32_t nc = 0;
+  for (int32_t cls = nc0 - 1; cls >= 0 && !st; --cls) {
+    for (int64_t i = 0; i < nloc; ++i) {
+      if (colors_owned[i] != cls) continue;
+      for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+        const int64_t c  = ci[k];
+        const int32_t cc = c == r0 + i ? -1 : (c >= r0 && c < r1 ? newc[c - r0] : gcol[bsearch_i64(gh, ngh, c)]);
+        if (cc >= 0 && cc <= maxdeg) mark[cc] = (int32_t)i; /* a colour above the row's degree cannot be the smallest free one */
+      }
+      int32_t col = 0;
+      while (col <= maxdeg && mark[col] == (int32_t)i) ++col;
+      newc[i] = col;
+      if (col + 1 > nc) nc = col + 1;
+    }
+    void *all = NULL;
+    st        = hc_allgatherv(comm, newc, (int64_t)sizeof(int32_t) * nloc, &all, offs);
+    st        = hc_agree(comm, st, "exchanging a colour class");
+    for (int64_t g = 0; g < ngh && !st; ++g) gcol[g] = ((const int32_t *)((const char *)all + offs[gown[g]]))[gh[g] - row_starts[gown[g]]];
+    free(all);
+  }
+  if (!st) {
+    memcpy(colors_owned, newc, sizeof(int32_t) * (size_t)nloc);
+    int32_t *all = (int32_t *)malloc(sizeof(int32_t) * (size_t)np);
+    if (!all) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
+    if (!st) st = hc_allgather(comm, &nc, sizeof nc, all);
+    for (int r = 0; r < np && !st; ++r)
+      if (all[r] > nc) nc = all[r];
+    free(all);
+  }
+  free(gh), free(offs), free(newc), free(mark), free(gcol), free(gown);
+  PMG_CALL(st);
+  *ncolors = nc;
+  return PMG_SUCCESS;
+}
+
 /* ---------------------------------------------------------------------------------------------------- */
 /* hierarchy distributed by row blocks                                                                    */
 /* ---------------------------------------------------------------------------------------------------- */
@@ -524,6 +597,7 @@ typedef struct {
 struct pmg_rbh_s {
   pmg_host_comm comm;
   int32_t       nlevels, fold, built;
+  int           coloring; /* rule of the levels without a caller's colouring: PMG_COLORING_GREEDY (0) or PMG_COLORING_ITERATED */
   int64_t       replicate_below;
   rbh_level    *lv;
 };
@@ -609,6 +683,17 @@ pmg_status pmg_rbh_set_level_interpolation(pmg_rbh h, int32_t level, int64_t nlo
 /* optional: the caller's colouring of its rows of `level` (e.g. PETSc's MatColoring as the reference applies it,
    src/mc_sor.c:383-395); must be a valid distance-1 colouring of the global matrix with the same ncolors on every rank.
    Default: the library's first-fit rule on the global matrix (pmg_rowblock_color_greedy). */
+/* rule of every level that gets no colouring of the caller's: PMG_COLORING_GREEDY (default) or PMG_COLORING_ITERATED -- row-block
+   levels through pmg_rowblock_color_greedy / _iterated, the replicated levels below the fold through pmg_mgmc_set_coloring */
+pmg_status pmg_rbh_set_coloring(pmg_rbh h, int rule)
+{
+  PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
+  PMG_CHECK(!h->built, PMG_ERR_ARG_WRONGSTATE, "the hierarchy is already built");
+  PMG_CHECK(rule == PMG_COLORING_GREEDY || rule == PMG_COLORING_ITERATED, PMG_ERR_ARG_OUTOFRANGE, "colouring rule %d: greedy or iterated expected", rule);
+  h->coloring = rule;
+  return PMG_SUCCESS;
+}
+
 pmg_status pmg_rbh_set_level_coloring(pmg_rbh h, int32_t level, int32_t ncolors, const int32_t *colors_owned)
 {
   PMG_CHECK(h, PMG_ERR_ARG_NULL, "null handle");
@@ -838,7 +923,7 @@ pmg_status pmg_rbh_build(pmg_rbh h)
       Lv->colors = (int32_t *)malloc(sizeof(int32_t) * (size_t)(Lv->nloc > 0 ? Lv->nloc : 1));
       if (!Lv->colors) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
       st = hc_agree(c, st, "allocating the colouring");
-      if (!st) st = pmg_rowblock_color_greedy(c, Lv->starts, Lv->A.rp, Lv->A.ci, Lv->colors, &Lv->ncolors);
+      if (!st) st = (h->coloring == PMG_COLORING_ITERATED ? pmg_rowblock_color_iterated : pmg_rowblock_color_greedy)(c, Lv->starts, Lv->A.rp, Lv->A.ci, Lv->colors, &Lv->ncolors);
     } else { /* the caller's: every rank must name the same number of colours */
       int32_t *all = (int32_t *)malloc(sizeof(int32_t) * (size_t)np);
       if (!all) st = pmg_set_error(PMG_ERR_MEM, __FILE__, __LINE__, "out of host memory");
@@ -972,6 +1057,7 @@ pmg_status pmg_rbh_create_mgmc(pmg_rbh h, pmg_dist transport, pmg_mgmc *out)
   *out        = NULL;
   pmg_mgmc mg = NULL;
   PMG_CALL(pmg_mgmc_create_hierarchy(h->nlevels, &mg));
+  PMG_CALL(pmg_mgmc_set_coloring(mg, h->coloring)); /* the replicated levels below the fold follow the hierarchy's rule */
   pmg_status st = PMG_SUCCESS;
   for (int l = 0; l < h->nlevels && !st; ++l) {
     pmg_rbh_level_view v;

@@ -104,6 +104,7 @@ pmg_status pmg_dist_destroy(pmg_dist *d)
   return PMG_SUCCESS;
 }
 STUB(pmg_mgmc_create_hierarchy, int32_t l, pmg_mgmc *m)
+STUB(pmg_mgmc_set_coloring, pmg_mgmc m, int rule)
 STUB(pmg_mgmc_set_level_operator, pmg_mgmc m, int32_t l, int32_t n, const int32_t *a, const int32_t *b, const double *c)
 STUB(pmg_mgmc_set_level_interpolation, pmg_mgmc m, int32_t l, int32_t n, int32_t k, const int32_t *a, const int32_t *b, const double *c)
 STUB(pmg_mgmc_set_rowblock_transport, pmg_mgmc m, pmg_dist d, const int64_t *c)

@@ -258,3 +258,61 @@ def test_tiny_block_beside_a_clique():
         p.join(timeout=60)
     for r, msg in sorted(res):
         assert msg == "ok", f"rank {r}:\n{msg}"
+
+
+def _iterated_worker(rank, world, port, q):
+    """the distributed second colouring round (pmg_rowblock_color_iterated) == the one-process rule (oracle twin of
+    PMG_COLORING_ITERATED) on the P1 matrix of lshape.msh refined twice and on its first Galerkin level, uneven row blocks"""
+    import torch.distributed as dist
+
+    from parmgmc_amd import capi
+    from parmgmc_amd.capi import check, lib
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm, keep = capi.torch_host_comm(rank, world)
+        ops, _ = problem()
+        fewer = 0
+        for op in ops[-2:]:
+            n = len(op[0]) - 1
+            A = sp.csr_matrix((op[2], op[1], op[0]), shape=(n, n))
+            A.sort_indices()
+            cuts = [0] + [int(n * f) for f in np.cumsum([0.5, 0.1, 0.25, 0.15][:world - 1])] + [n] if world > 1 else [0, n]
+            starts = np.array(cuts, np.int64)
+            r0, r1 = int(starts[rank]), int(starts[rank + 1])
+            mine = A[r0:r1].tocsr()
+            rp, ci = np.ascontiguousarray(mine.indptr, np.int64), np.ascontiguousarray(mine.indices, np.int64)
+            csr = O.CSR.from_scipy(A)
+            for fn, want in ((lib.pmg_rowblock_color_greedy, O.coloring_greedy(csr)), (lib.pmg_rowblock_color_iterated, O.coloring_iterated(csr))):
+                cols = np.full(r1 - r0, -7, np.int32)
+                nc = C.c_int32()
+                check(fn(C.byref(comm), starts.ctypes.data, rp.ctypes.data, ci.ctypes.data, cols.ctypes.data, C.byref(nc)))
+                assert np.array_equal(cols, want[r0:r1]) and nc.value == int(want.max()) + 1, (rank, n, nc.value)
+            fewer += int(O.coloring_iterated(csr).max() < O.coloring_greedy(csr).max())
+        assert fewer >= 1  # the second round saves a class on at least one of the two matrices
+        q.put((rank, "ok"))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_distributed_iterated_colouring_equals_the_one_process_rule(world):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_iterated_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r, msg in sorted(res):
+        assert msg == "ok", f"rank {r}:\n{msg}"
