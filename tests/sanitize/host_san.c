@@ -137,6 +137,7 @@ static void *san_rank(void *arg)
   intptr_t      fail = 0;
   pmg_rbh       h    = NULL;
   if (pmg_rbh_create(&hc, 3, 40, &h)) return (void *)1;
+  if (pmg_rbh_set_coloring(h, PMG_COLORING_ITERATED)) return (void *)1; /* first-fit + the second round with its per-class exchanges (round 4): both under the sanitizers; the build checks the result */
   for (int l = 0; l < 3 && !fail; ++l) {
     const int64_t r0 = n[l] * rank / SAN_RANKS, r1 = n[l] * (rank + 1) / SAN_RANKS, nl = r1 - r0;
     int64_t      *rp = malloc(sizeof(int64_t) * (size_t)(nl + 1)), *ci = malloc(sizeof(int64_t) * (size_t)(5 * nl));
