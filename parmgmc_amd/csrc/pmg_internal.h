@@ -71,6 +71,7 @@ pmg_status pmg_lrc_get_compact(pmg_lrc l, int32_t *k, int64_t *ns, int64_t *rows
 pmg_lrc    pmg_grid_lrc(pmg_grid g); /* the grid operator's low-rank update, NULL if none (borrowed) */
 void       pmg_lrc_destroy(pmg_lrc *l);
 pmg_status pmg_mcsor_set_idiag_by_division(pmg_mcsor mc, int on); /* PCPARSOR's idiag = omega / d */
+pmg_status pmg_mcsor_set_natural_order(pmg_mcsor mc, int on); /* no locality renumbering inside the colours (hierarchy levels) */
 /* pmg_parsor.c: data-flow form of PCPARSOR's multi-rank sweep; the four arrays are malloc'ed, the caller frees them */
 pmg_status pmg_parsor_build_dataflow(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, int32_t nparts, const int32_t *row_starts, const int32_t *proccols_in, int32_t **e_rowptr, int32_t **e_colidx, double **e_vals, int32_t **e_colors, int32_t *nlevels_out, int32_t *proccols_out, int32_t *classes_out);
 int        pmg_invert_small(int k, double *a_colmajor, double *inv); /* Gauss-Jordan, partial pivoting; a is overwritten; nonzero = singular */

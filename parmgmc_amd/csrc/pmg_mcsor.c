@@ -20,6 +20,7 @@ struct pmg_mcsor_s {
   /* options */
   double   omega;
   int      omega_changed;
+  int      natural_order;     /* 1: rows ascending inside a colour whatever their locality (levels of a hierarchy: pmg_mcsor_set_natural_order) */
   int      idiag_by_division; /* PCPARSOR's rule: omega / d in one rounding (src/pc_parsor.c:69-81) instead of (1/d) * omega */
   int      type;
   int      rule;
@@ -102,6 +103,59 @@ static pmg_status color_iterated(pmg_mcsor mc)
   mc->ncolors = nc;
   free(first), free(order), free(mark), free(newc);
   return PMG_SUCCESS;
+}
+
+/* In which order the rows of a colour are laid out is nobody's business but the gathers': a row's update does not depend on its
+   position (the sum runs in the row's own storage order, the noise is keyed on the row's original number), so any order inside a
+   colour gives the same bits.  The caller's numbering decides how far apart in memory the y[col] of a row lie -- the node
+   numbering uniform mesh refinement leaves (old nodes first, new ones appended level after level) is the worst case: the sliced-
+   ELL sweep then moves 1.6 x its algorithmic bytes.  A breadth-first numbering of the matrix graph (Cuthill-McKee without the
+   degree sort) puts neighbours next to each other; it is used when it shortens the total index distance sum |pos(r) - pos(c)|
+   over the stored entries to less than 0.7 of the natural order's (structured and mesher-ordered matrices keep their own).
+   Returns the visiting sequence (malloc'ed) or NULL for the natural order.  PMG_SELL_LOCALITY=0 never, 2 always. */
+static int32_t *locality_order(int32_t n, const int32_t *rowptr, const int32_t *colidx)
+{
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("PMG_SELL_LOCALITY");
+    env           = e ? atoi(e) : 1;
+  }
+  if (!env || n < 4096) return NULL; /* small matrices live in the L2 whatever their numbering */
+  int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *rank = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  if (!order || !rank) {
+    free(order), free(rank);
+    return NULL;
+  }
+  for (int32_t r = 0; r < n; ++r) rank[r] = -1;
+  int32_t head = 0, tail = 0;
+  for (int32_t s = 0; s < n; ++s) { /* every component, from its lowest row */
+    if (rank[s] >= 0) continue;
+    rank[s]       = tail;
+    order[tail++] = s;
+    while (head < tail) {
+      const int32_t r = order[head++];
+      for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int32_t c = colidx[k];
+        if (rank[c] < 0) {
+          rank[c]       = tail;
+          order[tail++] = c;
+        }
+      }
+    }
+  }
+  double dn = 0.0, db = 0.0;
+  for (int32_t r = 0; r < n; ++r)
+    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const int32_t c = colidx[k];
+      dn += (double)(r > c ? r - c : c - r);
+      db += (double)(rank[r] > rank[c] ? rank[r] - rank[c] : rank[c] - rank[r]);
+    }
+  free(rank);
+  if (env < 2 && !(db < 0.7 * dn)) {
+    free(order);
+    return NULL;
+  }
+  return order;
 }
 
 /* level(r) = 1 + max level of the neighbours that precede r: sweeping the levels in ascending order is the
@@ -303,7 +357,9 @@ pmg_status pmg_mcsor_setup(pmg_mcsor mc)
     mc->orig_host[r] = -1;
     mc->diag_host[r] = 1.0;
   }
-  for (int32_t r = 0; r < n; ++r) { /* rows ascending inside a colour, as ISColoringGetIS lists them */
+  int32_t *visit = mc->rule == PMG_COLORING_LEXLEVELS || mc->natural_order ? NULL : locality_order(n, mc->rowptr, mc->colidx); /* NULL: rows ascending inside a colour, as ISColoringGetIS lists them */
+  for (int32_t q = 0; q < n; ++q) {
+    const int32_t r  = visit ? visit[q] : q;
     const int32_t c  = mc->colors[r];
     const int32_t nr = mc->cslice[c] * 64 + fill[c]++;
     newidx[r]        = nr;
@@ -349,6 +405,7 @@ pmg_status pmg_mcsor_setup(pmg_mcsor mc)
   free(newidx);
   free(fill);
   free(count);
+  free(visit);
 
   mc->S.n       = n;
   mc->S.ld      = ld;
@@ -380,6 +437,17 @@ pmg_status pmg_mcsor_setup(pmg_mcsor mc)
   /* the borrowed CSR is no longer needed */
   mc->rowptr = mc->colidx = NULL;
   mc->vals            = NULL;
+  return PMG_SUCCESS;
+}
+
+/* internal: keep the caller's row order inside the colours (no locality renumbering).  The levels of a hierarchy: their
+   transfers read and write the level vectors through the same layout, and on the bench's aggregation hierarchy the breadth-
+   first layout that speeds the stand-alone sweep up by 5 % made the whole MGMC sample 1.7 % slower (0.2324 -> 0.2365 ms). */
+pmg_status pmg_mcsor_set_natural_order(pmg_mcsor mc, int on)
+{
+  PMG_CHECK(mc, PMG_ERR_ARG_NULL, "null MCSOR");
+  PMG_CHECK(!mc->is_setup, PMG_ERR_ARG_WRONGSTATE, "before pmg_mcsor_setup");
+  mc->natural_order = on;
   return PMG_SUCCESS;
 }
 

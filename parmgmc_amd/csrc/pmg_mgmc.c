@@ -835,6 +835,7 @@ static pmg_status mgmc_setup_user(pmg_mgmc h)
     PMG_CHECK(pos[l], PMG_ERR_MEM, "out of host memory");
     if (l > 0 || h->coarse_type == 1) {
       PMG_CALL(pmg_mcsor_create_csr(Lv->n, Lv->A_user.rp, Lv->A_user.ci, Lv->A_user.v, &Lv->mc));
+      PMG_CALL(pmg_mcsor_set_natural_order(Lv->mc, 1));
       Lv->A_nnz = Lv->A_user.rp[Lv->n];
       if (Lv->rb) { /* the caller's global colouring on the owned rows, the ghost rows in a colour of their own that is never swept */
         PMG_CHECK(Lv->rb_nowned <= Lv->n, PMG_ERR_ARG_SIZ, "level %d: %d owned rows of %d local rows", l, Lv->rb_nowned, Lv->n);
@@ -1066,6 +1067,7 @@ pmg_status pmg_mgmc_setup(pmg_mgmc h)
         for (int32_t j = 0; j < Cc->ny; ++j)
           for (int32_t i = 0; i < Cc->nx; ++i) col[i + Cc->nx * (j + Cc->ny * k)] = remap[(i & 1) + 2 * (j & 1) + 4 * (k & 1)];
       PMG_CALL(pmg_mcsor_create_csr(Cc->n, Ac.rp, Ac.ci, Ac.v, &Cc->mc));
+      PMG_CALL(pmg_mcsor_set_natural_order(Cc->mc, 1));
       Cc->A_nnz = Ac.rp[Cc->n];
       PMG_CALL(pmg_mcsor_set_coloring(Cc->mc, PMG_COLORING_USER, col));
       PMG_CALL(pmg_mcsor_set_omega(Cc->mc, h->omega));
